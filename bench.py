@@ -1,0 +1,157 @@
+#!/usr/bin/env python
+"""bench.py -- images/s of the ViT forward path on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one forward of the hot path (patch-embed .. class softmax) over one batch of
+synthetic 224x224x3 images already resident in HBM, through the C ABI of libvitx.so.
+N>1: one process per GPU, images sharded by batch (weak scaling: 256 per GPU), weights
+replicated, and ONE RCCL all-gather of the [256,1000] class probabilities per step.
+Prints one JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = 2516.6      # dense bf16/fp16 MFMA, 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH: ~2.5 PF)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="vit_base_patch16_224")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import _pkg
+    pkg = _pkg.load()
+    from vitcpp_amd import binding
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # weights: random-init of the named architecture in the reference's file format
+    if rank == 0:
+        path = pkg.synth.cached_synthetic(args.model, head_scale=8.0)
+    if dist is not None:
+        dist.barrier()
+    path = pkg.synth.cached_synthetic(args.model, head_scale=8.0)
+    hp = pkg.synth.hparams_for(args.model)
+    gflop = pkg.synth.gflop_per_image(hp)
+    S, C, B = hp.img_size, hp.num_classes, args.batch
+
+    model = binding.Model(path)
+    dt = binding.BF16 if args.dtype == "bf16" else binding.F16
+    ctx = binding.Context(model, device=local_rank, max_batch=B, dtype=dt)
+
+    # synthetic batch resident in HBM: u8 noise -> (v-mean)/std f32 HWC, what vit_image_preprocess emits
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    u8 = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(pkg.synth.IMAGENET_MEAN); std = torch.tensor(pkg.synth.IMAGENET_STD)
+    imgs = ((u8.float() - mean) / std).contiguous().cuda()
+    probs = torch.empty((B, C), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((world * B, C), dtype=torch.float32, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.forward_device(imgs.data_ptr(), B, probs.data_ptr(), 0, stream)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, probs)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read() if not args.no_profile else []
+    ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sanity = probs.sum(1)
+    assert torch.isfinite(probs).all() and float((sanity - 1).abs().max()) < 1e-3, "forward produced invalid probabilities"
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        out = {
+            "metric": "images/sec ViT-B/16 224^2 bs=256 per GPU (forward, synthetic, HBM-resident inputs)",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.dtype}, batch={B} per GPU, {S}x{S}x3 f32 HWC inputs in HBM, random-init weights in the reference's file format",
+                       "global_batch": world * B, "parallelism": f"dp{world} (batch shards, replicated weights, 1 all-gather of probs/step)" if world > 1 else "single GPU"},
+            "gflop_per_image": round(gflop, 4),
+            "mfma_roofline_frac_whole_forward": round(value / world * gflop / 1e3 / PEAK_TFLOPS, 4),
+        }
+        # roofline of the dominant kernel: algorithmic flops / HIP-event time on the launch stream
+        if prof:
+            kern = {p["name"]: p for p in prof}
+            gemms = [p for p in prof if p["name"].startswith("gemm_")]
+            dom = max(gemms, key=lambda p: p["total_ms"])
+            tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "flops_per_launch": dom["flops"] / dom["launches"]}
+            tot = sum(p["total_ms"] for p in prof)
+            out["kernel_breakdown"] = {p["name"]: {"ms_per_step": round(p["total_ms"] / args.steps, 4), "share": round(p["total_ms"] / tot, 4),
+                                                    "TFLOPs": round(p["flops"] / (p["total_ms"] * 1e-3) / 1e12, 1) if p["flops"] else None,
+                                                    "GBps_algorithmic": round(p["bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1)} for p in prof}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            om = O.OracleModel(path)
+            n_cpu = args.cpu_images
+            cpu_imgs = imgs[:n_cpu].cpu().numpy()
+            t1 = time.perf_counter()
+            om.forward(cpu_imgs, O.REF)
+            dtc = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(n_cpu / dtc, 3), "unit": "images/s", "cores": O.num_threads(), "kind": "port",
+                                   "sample": f"{n_cpu} images of the same batch through oracle/vit_oracle.c (ggml-semantics restatement, OpenMP, NOT ggml itself), {dtc:.1f} s"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

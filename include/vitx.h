@@ -1,0 +1,140 @@
+/*
+ * vitx.h -- C ABI of the MI355X-native ViT forward engine (libvitx.so).
+ *
+ * This is the drop-in boundary for the forward path of staghado/vit.cpp.  The
+ * reference exposes three C++ entry points (vit.h:119-122):
+ *     bool vit_model_load(const std::string&, vit_model&);                      vit.h:120
+ *     bool vit_image_preprocess(const image_u8&, image_f32&, const vit_hparams&); vit.h:119
+ *     int  vit_predict(const vit_model&, vit_state&, const image_f32,
+ *                      const vit_params&, std::vector<std::pair<float,int>>&);  vit.h:122
+ * The C++ mirror of those signatures lives in vit.cpp_amd/vit.h and is a thin
+ * wrapper over the functions below (plain pointers and sizes, int status codes,
+ * caller-owned output buffers, no exceptions across the ABI).  INTEGRATION.md
+ * shows the binding a maintainer of the reference would add.
+ *
+ * Threading: a vitx_model is immutable after load and may be shared; a vitx_ctx
+ * is per (thread, GPU) mutable scratch -- the analogue of vit_state (vit.h:72-80).
+ */
+#ifndef VITX_H
+#define VITX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vitx_model vitx_model;
+typedef struct vitx_ctx vitx_ctx;
+
+enum vitx_status {
+    VITX_OK = 0,
+    VITX_ERR_IO = 1,          /* cannot open / short read                         (vit.cpp:312-317) */
+    VITX_ERR_FORMAT = 2,      /* bad magic, unknown tensor, wrong shape or size   (vit.cpp:320-328, 618-685, 697-701) */
+    VITX_ERR_ARG = 3,         /* NULL pointer, batch > max_batch, wrong image size (vit.cpp:757) */
+    VITX_ERR_HIP = 4,         /* a HIP runtime call or kernel launch failed */
+    VITX_ERR_UNSUPPORTED = 5, /* model shape the kernels do not cover */
+    VITX_ERR_NOMEM = 6
+};
+
+/* Arithmetic type of the MFMA operands (accumulation, LayerNorm, softmax and the
+ * residual stream are always f32).  F16 reproduces the reference's rounding points
+ * (ggml rounds mul_mat activations to fp16); BF16 is the mode BASELINE.json names. */
+enum vitx_dtype { VITX_F16 = 0, VITX_BF16 = 1 };
+
+/* Interpolation of vit_image_preprocess (vit_hparams::interpolation, vit.h:30). */
+enum vitx_interp { VITX_BICUBIC = 0, VITX_BILINEAR = 1 };
+
+/* Mirrors vit_hparams (vit.h:20-37); eps is not stored in the file (always 1e-6). */
+typedef struct vitx_hparams {
+    int32_t hidden_size;
+    int32_t num_hidden_layers;
+    int32_t num_attention_heads;
+    int32_t num_classes;
+    int32_t patch_size;
+    int32_t img_size;
+    int32_t ftype;
+    float eps;
+} vitx_hparams;
+
+const char *vitx_status_str(int status);
+/* Thread-local description of the last error raised on this thread ("" if none). */
+const char *vitx_last_error(void);
+
+/* ---- model file (replaces vit_model_load, vit.cpp:308-712) ------------------ */
+/* Parses the legacy-ggml ".gguf" file into host memory; validates magic, names,
+ * shapes and byte sizes exactly where the reference does.  No GPU is touched. */
+int vitx_model_load(const char *path, vitx_model **out);
+void vitx_model_free(vitx_model *m);
+int vitx_model_hparams(const vitx_model *m, vitx_hparams *out);
+int vitx_model_num_labels(const vitx_model *m);
+/* id2label lookup (vit.cpp:1065 uses .at(idx)); NULL when the id has no label. */
+const char *vitx_model_label(const vitx_model *m, int class_id);
+int vitx_model_num_tensors(const vitx_model *m);
+/* Name, file type code (0 f32,1 f16,2 q4_0,3 q4_1,6 q5_0,7 q5_1,8 q8_0), ggml-order dims. */
+int vitx_model_tensor_info(const vitx_model *m, int index, const char **name, int32_t *type, int64_t ne[4], size_t *nbytes);
+/* Decodes tensor `index` to f32 into out (n_elements floats).  Host only. */
+int vitx_model_tensor_f32(const vitx_model *m, int index, float *out, size_t n_elements);
+
+/* ---- preprocess (replaces vit_image_preprocess, vit.cpp:289-305) ------------ */
+/* u8 HWC RGB [ny][nx][3] -> f32 HWC [img_size][img_size][3], resized without
+ * crop/antialias, rounded to u8, ImageNet mean/std normalised (vit.cpp:130-287). */
+int vitx_preprocess_u8(const uint8_t *hwc, int nx, int ny, int img_size, int interp, float *out_hwc);
+
+/* ---- execution context (replaces vit_state + the per-call graph build) ------ */
+/* Uploads the weights to `device` in `dtype` and allocates all activation scratch
+ * for up to max_batch images once (the reference reallocates per call, vit.cpp:1009-1035). */
+int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out);
+void vitx_ctx_free(vitx_ctx *c);
+int vitx_ctx_max_batch(const vitx_ctx *c);
+
+/* Forward pass (replaces vit_encode_image + the compute half of vit_predict,
+ * vit.cpp:718-941, 1028-1040) on n <= max_batch images.
+ *   imgs_hwc : n x [img_size][img_size][3] f32, as vit_image_preprocess emits
+ *   probs    : n x num_classes f32 class probabilities (state.prediction)
+ *   logits   : optional (may be NULL), pre-softmax
+ * vitx_forward takes host pointers (copies in/out and synchronises);
+ * vitx_forward_device takes device pointers and only enqueues on `stream`
+ * (a hipStream_t, NULL = the context's own stream). */
+int vitx_forward(vitx_ctx *c, const float *imgs_hwc, int n, float *probs, float *logits);
+int vitx_forward_device(vitx_ctx *c, const void *d_imgs_hwc, int n, void *d_probs, void *d_logits, void *stream);
+int vitx_ctx_synchronize(vitx_ctx *c);
+
+/* Sorted top-k of one probability row (vit.cpp:1043-1057: descending by prob). */
+int vitx_topk(const float *probs, int num_classes, int k, int32_t *out_idx, float *out_prob);
+
+/* ---- measurement ------------------------------------------------------------ */
+/* When enabled, every kernel launch of vitx_forward_device is bracketed by HIP
+ * events on the launch stream; vitx_profile_read() synchronises, folds the event
+ * pairs into per-kernel-class totals and clears the pool. */
+#define VITX_PROF_MAX_CLASSES 16
+typedef struct vitx_prof_entry {
+    const char *name;     /* kernel class, e.g. "gemm_fc1_gelu" */
+    int32_t launches;
+    double total_ms;
+    double flops;         /* algorithmic 2*M*N*K summed over the launches (0 for non-GEMM classes) */
+    double bytes;         /* algorithmic HBM bytes summed over the launches */
+} vitx_prof_entry;
+int vitx_profile_enable(vitx_ctx *c, int on);
+int vitx_profile_read(vitx_ctx *c, vitx_prof_entry *out, int max_entries, int *n_entries);
+
+/* ---- single-kernel entry points (device pointers; used by the parity tests) - */
+/* y[M][N] (dtype) = LayerNorm(x[M][D] f32) * w + b, eps inside the sqrt (vit.cpp:808-812). */
+int vitx_op_layernorm(int dtype, const void *d_x, const void *d_w, const void *d_b, void *d_y, int M, int D, float eps, void *stream);
+/* C = A[M][K] . W[N][K]^T with a fused epilogue; A, W in `dtype`.
+ *   epi 0: out dtype  = acc + bias                  (vit.cpp:820-821)
+ *   epi 1: out dtype  = gelu_tanh(acc + bias)       (vit.cpp:889-893)
+ *   epi 2: out f32    = (acc + bias) + out  in place (vit.cpp:868-873, 896-900)
+ *   epi 3: out f32    = acc + bias                  (vit.cpp:927-928)
+ * M must be a multiple of 128 rows allocated; N, K multiples of 64. */
+int vitx_op_gemm(int dtype, int epi, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int M, int N, int K, void *stream);
+/* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
+int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
+/* probs = softmax(logits) over num_classes with the reference's fp16 exp rounding (vit.cpp:931). */
+int vitx_op_softmax(const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITX_H */

@@ -1,0 +1,186 @@
+"""ctypes binding over the C ABI of libvitx.so (include/vitx.h).
+
+Plumbing for tests/ and bench.py: PyTorch provides device memory and streams,
+every computation happens inside libvitx.so.  There is NO fallback: if the HIP
+library is missing or no GPU is present, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitx.so")
+
+F16, BF16 = 0, 1
+BICUBIC, BILINEAR = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32 = 0, 1, 2, 3
+
+EXPORTS = [
+    "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
+    "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_preprocess_u8",
+    "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
+    "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_attention", "vitx_op_softmax",
+]
+
+
+class HParams(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("num_hidden_layers", C.c_int32), ("num_attention_heads", C.c_int32), ("num_classes", C.c_int32),
+                ("patch_size", C.c_int32), ("img_size", C.c_int32), ("ftype", C.c_int32), ("eps", C.c_float)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int32), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class VitxError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile libvitx.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _HERE, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VitxError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp, ip = C.c_void_p, C.c_int
+        L.vitx_status_str.restype = C.c_char_p; L.vitx_status_str.argtypes = [ip]
+        L.vitx_last_error.restype = C.c_char_p
+        L.vitx_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.vitx_model_free.argtypes = [vp]
+        L.vitx_model_hparams.argtypes = [vp, C.POINTER(HParams)]
+        L.vitx_model_num_labels.argtypes = [vp]
+        L.vitx_model_label.restype = C.c_char_p; L.vitx_model_label.argtypes = [vp, ip]
+        L.vitx_model_num_tensors.argtypes = [vp]
+        L.vitx_model_tensor_info.argtypes = [vp, ip, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_size_t)]
+        L.vitx_model_tensor_f32.argtypes = [vp, ip, C.POINTER(C.c_float), C.c_size_t]
+        L.vitx_preprocess_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, ip, C.POINTER(C.c_float)]
+        L.vitx_ctx_create.argtypes = [vp, ip, ip, ip, C.POINTER(vp)]
+        L.vitx_ctx_free.argtypes = [vp]
+        L.vitx_ctx_max_batch.argtypes = [vp]
+        L.vitx_forward.argtypes = [vp, C.POINTER(C.c_float), ip, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.vitx_forward_device.argtypes = [vp, vp, ip, vp, vp, vp]
+        L.vitx_ctx_synchronize.argtypes = [vp]
+        L.vitx_topk.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        L.vitx_profile_enable.argtypes = [vp, ip]
+        L.vitx_profile_read.argtypes = [vp, C.POINTER(ProfEntry), ip, C.POINTER(ip)]
+        L.vitx_op_layernorm.argtypes = [ip, vp, vp, vp, vp, ip, ip, C.c_float, vp]
+        L.vitx_op_gemm.argtypes = [ip, ip, vp, vp, vp, vp, ip, ip, ip, vp]
+        L.vitx_op_attention.argtypes = [ip, vp, vp, ip, ip, ip, ip, vp]
+        L.vitx_op_softmax.argtypes = [vp, vp, ip, ip, ip, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        L = lib()
+        raise VitxError(f"{what}: {L.vitx_status_str(rc).decode()} ({rc}): {L.vitx_last_error().decode()}")
+
+
+class Model:
+    """Parsed weight file (vit_model_load, vit.cpp:308-712)."""
+
+    def __init__(self, path: str):
+        self._h = C.c_void_p()
+        check(lib().vitx_model_load(path.encode(), C.byref(self._h)), f"vitx_model_load({path})")
+        hp = HParams(); lib().vitx_model_hparams(self._h, C.byref(hp))
+        self.hparams = hp
+        self.path = path
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h:
+            lib().vitx_model_free(self._h); self._h = C.c_void_p()
+
+    __del__ = close
+
+    @property
+    def num_classes(self) -> int: return self.hparams.num_classes
+    @property
+    def img_size(self) -> int: return self.hparams.img_size
+
+    def label(self, i: int) -> Optional[str]:
+        s = lib().vitx_model_label(self._h, i)
+        return s.decode() if s is not None else None
+
+    def tensors(self) -> List[Tuple[str, int, Tuple[int, ...], int]]:
+        out = []
+        for i in range(lib().vitx_model_num_tensors(self._h)):
+            name = C.c_char_p(); t = C.c_int32(); ne = (C.c_int64 * 4)(); nb = C.c_size_t()
+            check(lib().vitx_model_tensor_info(self._h, i, C.byref(name), C.byref(t), ne, C.byref(nb)))
+            out.append((name.value.decode(), t.value, tuple(ne), nb.value))
+        return out
+
+    def tensor_f32(self, index: int) -> np.ndarray:
+        _, _, ne, _ = self.tensors()[index]
+        n = int(np.prod(ne)); a = np.empty(n, np.float32)
+        check(lib().vitx_model_tensor_f32(self._h, index, a.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return a.reshape(tuple(reversed(ne)))
+
+
+def preprocess(img_u8: np.ndarray, img_size: int, interp: int = BICUBIC) -> np.ndarray:
+    """vit_image_preprocess (vit.cpp:289-305): HWC u8 any size -> HWC f32 [S,S,3]."""
+    img = np.ascontiguousarray(img_u8, np.uint8); ny, nx = img.shape[:2]
+    out = np.empty((img_size, img_size, 3), np.float32)
+    check(lib().vitx_preprocess_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), nx, ny, img_size, interp, out.ctypes.data_as(C.POINTER(C.c_float))), "vitx_preprocess_u8")
+    return out
+
+
+class Context:
+    """Per-(thread, GPU) execution context (vit_state): weights in HBM + activation scratch."""
+
+    def __init__(self, model: Model, device: int = 0, max_batch: int = 1, dtype: int = F16):
+        self.model = model; self.device = device; self.max_batch = max_batch; self.dtype = dtype
+        self._h = C.c_void_p()
+        check(lib().vitx_ctx_create(model._h, device, max_batch, dtype, C.byref(self._h)), "vitx_ctx_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h:
+            lib().vitx_ctx_free(self._h); self._h = C.c_void_p()
+
+    __del__ = close
+
+    def forward(self, imgs_hwc: np.ndarray, want_logits: bool = False):
+        """Host arrays in/out (copies + sync): [n,S,S,3] f32 -> probs [n,C] (and logits)."""
+        x = np.ascontiguousarray(imgs_hwc, np.float32); n = x.shape[0]
+        probs = np.empty((n, self.model.num_classes), np.float32)
+        logits = np.empty_like(probs) if want_logits else None
+        fp = C.POINTER(C.c_float)
+        check(lib().vitx_forward(self._h, x.ctypes.data_as(fp), n, probs.ctypes.data_as(fp), logits.ctypes.data_as(fp) if want_logits else None), "vitx_forward")
+        return (probs, logits) if want_logits else probs
+
+    def forward_device(self, d_imgs: int, n: int, d_probs: int, d_logits: int = 0, stream: int = 0) -> None:
+        """Device pointers; only enqueues on `stream` (0 = the context's own stream)."""
+        check(lib().vitx_forward_device(self._h, d_imgs, n, d_probs, d_logits or None, stream or None), "vitx_forward_device")
+
+    def synchronize(self) -> None:
+        check(lib().vitx_ctx_synchronize(self._h), "vitx_ctx_synchronize")
+
+    def profile_enable(self, on: bool = True) -> None:
+        check(lib().vitx_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        arr = (ProfEntry * 16)(); n = C.c_int()
+        check(lib().vitx_profile_read(self._h, arr, 16, C.byref(n)), "vitx_profile_read")
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n.value)]
+
+
+def topk(probs_row: np.ndarray, k: int = 5):
+    p = np.ascontiguousarray(probs_row, np.float32); k = min(k, p.size)
+    idx = (C.c_int32 * k)(); val = (C.c_float * k)()
+    check(lib().vitx_topk(p.ctypes.data_as(C.POINTER(C.c_float)), p.size, k, idx, val), "vitx_topk")
+    return list(idx), list(val)

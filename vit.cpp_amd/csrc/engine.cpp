@@ -1,0 +1,358 @@
+// engine.cpp -- execution context and forward pass of the MI355X ViT engine.
+//
+// Replaces vit_state + vit_encode_image + the compute half of vit_predict
+// (/root/reference/vit.cpp:718-941, 1004-1040).  Differences by design: the batch is
+// n images (the reference hard-wires 1, vit.cpp:747), weights live in HBM in the MFMA
+// operand type, all activation scratch is allocated once per context (the reference
+// builds the graph twice and reallocates per call, vit.cpp:1009-1035), and the ~90
+// launches of a forward are enqueued on one HIP stream without host synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "model_file.h"
+
+using namespace vitx;
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return VITX_ERR_HIP; } \
+    } while (0)
+
+namespace {
+
+enum ProfClass {
+    PC_PATCHIFY = 0, PC_GEMM_PATCH, PC_CLS, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_GEMM_PROJ, PC_GEMM_FC1, PC_GEMM_FC2,
+    PC_GEMM_HEAD, PC_SOFTMAX, PC_COUNT
+};
+const char *kProfNames[PC_COUNT] = {"patchify", "gemm_patch_embed", "cls_rows", "layernorm", "gemm_qkv_bias", "attention", "gemm_proj_resid",
+                                    "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_head", "softmax"};
+
+struct LayerW {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct vitx_ctx {
+    const vitx_model *model = nullptr;
+    vitx_hparams hp{};
+    int device = 0, dtype = VITX_F16, max_batch = 0;
+    int D = 0, L = 0, H = 0, C = 0, P = 0, S = 0, g = 0, N = 0, Kpe = 0, Kpe_pad = 0, C_pad = 0;
+    int tm = 128, tn = 128;
+    hipStream_t stream = nullptr;
+    std::vector<void *> allocs;
+    // weights
+    float *cls = nullptr, *pos = nullptr, *pe_b = nullptr, *norm_w = nullptr, *norm_b = nullptr, *head_b = nullptr;
+    void *pe_w = nullptr, *head_w = nullptr;
+    std::vector<LayerW> layers;
+    // activations
+    float *img = nullptr;        // [max_batch][S][S][3] staging for the host entry point
+    float *X = nullptr;          // [Mpad][D] f32 residual stream
+    void *U = nullptr;           // [Mpad][D] LN output / attention output
+    void *QKV = nullptr;         // [Mpad][3D]
+    void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
+    void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
+    float *logits = nullptr;     // [Bpad][C_pad]
+    float *probs = nullptr;      // [max_batch][C]
+    // profiling
+    bool prof_on = false;
+    struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+
+    ~vitx_ctx() {
+        (void)hipSetDevice(device);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (void *p : allocs) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    int dmalloc(void **p, size_t bytes, bool zero) {
+        HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+        allocs.push_back(*p);
+        if (zero) HIP_TRY(hipMemset(*p, 0, bytes ? bytes : 16));
+        return VITX_OK;
+    }
+    hipEvent_t next_event() {
+        if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+        return ev_pool[ev_used++];
+    }
+};
+
+namespace {
+
+// f32 vector -> device f32 (padded with zeros to n_pad)
+int upload_f32(vitx_ctx *c, const HostTensor *t, float **out, size_t n_pad = 0) {
+    std::vector<float> h((size_t)t->nelements());
+    t->decode_f32(h.data());
+    if (n_pad > h.size()) h.resize(n_pad, 0.0f);
+    int rc = c->dmalloc((void **)out, h.size() * 4, false);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*out, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    return VITX_OK;
+}
+
+// [N][K] matrix -> operand type, rows padded to n_pad, cols to k_pad (zeros).  f16 file data is
+// forwarded bit-exact in F16 mode; everything else is decoded to f32 and rounded once (RNE).
+int upload_matrix(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad, int k_pad, void **out) {
+    std::vector<uint16_t> h((size_t)n_pad * k_pad, 0);
+    if (t->type == T_F16 && c->dtype == VITX_F16) {
+        const uint16_t *src = (const uint16_t *)t->raw.data();
+        for (int n = 0; n < Nrows; ++n) memcpy(&h[(size_t)n * k_pad], src + (size_t)n * K, (size_t)K * 2);
+    } else {
+        std::vector<float> f((size_t)Nrows * K);
+        t->decode_f32(f.data());
+        for (int n = 0; n < Nrows; ++n)
+            for (int k = 0; k < K; ++k)
+                h[(size_t)n * k_pad + k] = c->dtype == VITX_F16 ? f32_to_f16_bits(f[(size_t)n * K + k]) : f32_to_bf16_bits(f[(size_t)n * K + k]);
+    }
+    int rc = c->dmalloc(out, h.size() * 2, false);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*out, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return VITX_OK;
+}
+
+struct ProfScope {
+    vitx_ctx *c; hipStream_t s; size_t idx = 0; bool on;
+    ProfScope(vitx_ctx *c_, hipStream_t s_, int cls, double flops, double bytes) : c(c_), s(s_), on(c_->prof_on) {
+        if (!on) return;
+        vitx_ctx::Rec r{cls, c->next_event(), c->next_event(), flops, bytes};
+        idx = c->recs.size(); c->recs.push_back(r);
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() { if (on) (void)hipEventRecord(c->recs[idx].b, s); }
+};
+
+int gemm(vitx_ctx *c, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
+         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes) {
+    GemmArgs a{};
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
+    a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
+    double bytes = (double)M_real * K * 2 + (double)N * K * 2 + (double)M_real * N * out_elem_bytes;
+    if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
+    ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
+    HIP_TRY(launch_gemm(c->dtype, epi, a, st));
+    return VITX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out) {
+    if (!m || !out || max_batch <= 0 || (dtype != VITX_F16 && dtype != VITX_BF16)) { set_error("vitx_ctx_create: invalid argument"); return VITX_ERR_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("vitx_ctx_create: no HIP device available (this engine has no CPU fallback)"); return VITX_ERR_HIP; }
+    if (device < 0 || device >= ndev) { set_error("vitx_ctx_create: device %d out of range (%d devices)", device, ndev); return VITX_ERR_ARG; }
+    const vitx_hparams &hp = m->hp;
+    if (hp.hidden_size != hp.num_attention_heads * 64) { set_error("vitx_ctx_create: head_dim %d unsupported (kernels are written for 64)", hp.hidden_size / hp.num_attention_heads); return VITX_ERR_UNSUPPORTED; }
+    if (hp.hidden_size % 64) { set_error("vitx_ctx_create: hidden_size must be a multiple of 64"); return VITX_ERR_UNSUPPORTED; }
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<vitx_ctx> c(new (std::nothrow) vitx_ctx());
+    if (!c) return VITX_ERR_NOMEM;
+    c->model = m; c->hp = hp; c->device = device; c->dtype = dtype; c->max_batch = max_batch;
+    c->D = hp.hidden_size; c->L = hp.num_hidden_layers; c->H = hp.num_attention_heads; c->C = hp.num_classes; c->P = hp.patch_size; c->S = hp.img_size;
+    c->g = c->S / c->P; c->N = c->g * c->g + 1; c->Kpe = 3 * c->P * c->P; c->Kpe_pad = round_up(c->Kpe, 64);
+    c->tm = gemm_tile_m(); c->tn = gemm_tile_n();
+    c->C_pad = round_up(c->C, c->tn);
+    if ((c->N + 31) / 32 > 19) { set_error("vitx_ctx_create: %d tokens per image exceeds the single-pass attention kernel (max 608)", c->N); return VITX_ERR_UNSUPPORTED; }
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+    const int D = c->D, tn = c->tn;
+    int rc;
+    auto T = [&](const std::string &n) { return m->find(n); };
+    if ((rc = upload_f32(c.get(), T("cls_token"), &c->cls))) return rc;
+    if ((rc = upload_f32(c.get(), T("pos_embed"), &c->pos))) return rc;
+    if ((rc = upload_f32(c.get(), T("patch_embed.proj.bias"), &c->pe_b, round_up(D, tn)))) return rc;
+    if ((rc = upload_matrix(c.get(), T("patch_embed.proj.weight"), D, c->Kpe, round_up(D, tn), c->Kpe_pad, &c->pe_w))) return rc;
+    c->layers.resize(c->L);
+    for (int i = 0; i < c->L; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        LayerW &w = c->layers[i];
+        if ((rc = upload_f32(c.get(), T(p + "norm1.weight"), &w.ln1_w))) return rc;
+        if ((rc = upload_f32(c.get(), T(p + "norm1.bias"), &w.ln1_b))) return rc;
+        if ((rc = upload_f32(c.get(), T(p + "norm2.weight"), &w.ln2_w))) return rc;
+        if ((rc = upload_f32(c.get(), T(p + "norm2.bias"), &w.ln2_b))) return rc;
+        if ((rc = upload_f32(c.get(), T(p + "attn.qkv.bias"), &w.qkv_b, round_up(3 * D, tn)))) return rc;
+        if ((rc = upload_f32(c.get(), T(p + "attn.proj.bias"), &w.proj_b, round_up(D, tn)))) return rc;
+        if ((rc = upload_f32(c.get(), T(p + "mlp.fc1.bias"), &w.fc1_b, round_up(4 * D, tn)))) return rc;
+        if ((rc = upload_f32(c.get(), T(p + "mlp.fc2.bias"), &w.fc2_b, round_up(D, tn)))) return rc;
+        if ((rc = upload_matrix(c.get(), T(p + "attn.qkv.weight"), 3 * D, D, round_up(3 * D, tn), D, &w.qkv_w))) return rc;
+        if ((rc = upload_matrix(c.get(), T(p + "attn.proj.weight"), D, D, round_up(D, tn), D, &w.proj_w))) return rc;
+        if ((rc = upload_matrix(c.get(), T(p + "mlp.fc1.weight"), 4 * D, D, round_up(4 * D, tn), D, &w.fc1_w))) return rc;
+        if ((rc = upload_matrix(c.get(), T(p + "mlp.fc2.weight"), D, 4 * D, round_up(D, tn), 4 * D, &w.fc2_w))) return rc;
+    }
+    if ((rc = upload_f32(c.get(), T("norm.weight"), &c->norm_w))) return rc;
+    if ((rc = upload_f32(c.get(), T("norm.bias"), &c->norm_b))) return rc;
+    if ((rc = upload_f32(c.get(), T("head.bias"), &c->head_b, c->C_pad))) return rc;
+    if ((rc = upload_matrix(c.get(), T("head.weight"), c->C, D, c->C_pad, D, &c->head_w))) return rc;
+
+    const size_t Mpad = (size_t)round_up(max_batch * c->N, c->tm), Bpad = (size_t)round_up(max_batch, c->tm);
+    const size_t hcols = std::max<size_t>((size_t)4 * D, (size_t)c->Kpe_pad);
+    if ((rc = c->dmalloc((void **)&c->img, (size_t)max_batch * c->S * c->S * 3 * 4, false))) return rc;
+    if ((rc = c->dmalloc((void **)&c->X, Mpad * D * 4, true))) return rc;
+    if ((rc = c->dmalloc(&c->U, Mpad * D * 2, true))) return rc;
+    if ((rc = c->dmalloc(&c->QKV, Mpad * 3 * D * 2, true))) return rc;
+    if ((rc = c->dmalloc(&c->Hbuf, Mpad * hcols * 2, true))) return rc;
+    if ((rc = c->dmalloc(&c->Z, Bpad * D * 2, true))) return rc;
+    if ((rc = c->dmalloc((void **)&c->logits, Bpad * c->C_pad * 4, true))) return rc;
+    if ((rc = c->dmalloc((void **)&c->probs, (size_t)max_batch * c->C * 4, true))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    *out = c.release();
+    return VITX_OK;
+}
+
+void vitx_ctx_free(vitx_ctx *c) { delete c; }
+int vitx_ctx_max_batch(const vitx_ctx *c) { return c ? c->max_batch : 0; }
+
+int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, void *stream) {
+    if (!c || !d_imgs || !d_probs) { set_error("vitx_forward_device: NULL argument"); return VITX_ERR_ARG; }
+    if (n <= 0 || n > c->max_batch) { set_error("vitx_forward_device: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    const int D = c->D, N = c->N, tm = c->tm, tn = c->tn, dt = c->dtype;
+    const int tpi = c->g * c->g;
+    const int Mp_real = n * tpi, Mp = round_up(Mp_real, tm);       // patch rows
+    const int M_real = n * N, M = round_up(M_real, tm);            // token rows
+    const double eb = 2.0;                                          // operand bytes
+
+    // patch embedding: im2col -> GEMM(+bias, +pos, token scatter) ; cls rows      (vit.cpp:747-797)
+    {
+        ProfScope ps(c, st, PC_PATCHIFY, 0, (double)n * c->S * c->S * 3 * 4 + (double)Mp_real * c->Kpe_pad * eb);
+        HIP_TRY(launch_patchify(dt, (const float *)d_imgs, c->Hbuf, n, c->S, c->P, c->Kpe_pad, Mp, st));
+    }
+    int rc;
+    if ((rc = gemm(c, st, PC_GEMM_PATCH, EPI_PATCH, c->Hbuf, c->pe_w, c->pe_b, c->X, c->pos, Mp, Mp_real, D, round_up(D, tn), c->Kpe_pad,
+                   c->Kpe_pad, c->Kpe_pad, D, tpi, 4))) return rc;
+    {
+        ProfScope ps(c, st, PC_CLS, 0, (double)n * D * 4);
+        HIP_TRY(launch_cls_rows(c->cls, c->pos, c->X, n, N, D, st));
+    }
+    for (int il = 0; il < c->L; ++il) {
+        const LayerW &w = c->layers[il];
+        {   // norm1 (vit.cpp:808-812)
+            ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
+            HIP_TRY(launch_layernorm(dt, c->X, D, w.ln1_w, w.ln1_b, c->U, D, M_real, D, c->hp.eps, st));
+        }
+        // qkv projection (vit.cpp:820-821)
+        if ((rc = gemm(c, st, PC_GEMM_QKV, EPI_BIAS, c->U, w.qkv_w, w.qkv_b, c->QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2))) return rc;
+        {   // attention (vit.cpp:826-866)
+            ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
+            HIP_TRY(launch_attention(dt, c->QKV, c->U, n, N, D, c->H, st));
+        }
+        // output projection + residual (vit.cpp:868-873)
+        if ((rc = gemm(c, st, PC_GEMM_PROJ, EPI_BIAS_RESID, c->U, w.proj_w, w.proj_b, c->X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4))) return rc;
+        {   // norm2 (vit.cpp:881-885)
+            ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
+            HIP_TRY(launch_layernorm(dt, c->X, D, w.ln2_w, w.ln2_b, c->U, D, M_real, D, c->hp.eps, st));
+        }
+        // MLP (vit.cpp:889-900)
+        if ((rc = gemm(c, st, PC_GEMM_FC1, EPI_BIAS_GELU, c->U, w.fc1_w, w.fc1_b, c->Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2))) return rc;
+        if ((rc = gemm(c, st, PC_GEMM_FC2, EPI_BIAS_RESID, c->Hbuf, w.fc2_w, w.fc2_b, c->X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4))) return rc;
+    }
+    // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D
+    {
+        ProfScope ps(c, st, PC_LAYERNORM, 0, (double)n * D * (4 + eb));
+        HIP_TRY(launch_layernorm(dt, c->X, (long)N * D, c->norm_w, c->norm_b, c->Z, D, n, D, c->hp.eps, st));
+    }
+    // classifier (vit.cpp:927-928) and class softmax (vit.cpp:931-933)
+    float *lg = d_logits ? (float *)d_logits : c->logits;
+    const int ldl = d_logits ? c->C : c->C_pad;
+    if ((rc = gemm(c, st, PC_GEMM_HEAD, EPI_BIAS_F32, c->Z, c->head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4))) return rc;
+    {
+        ProfScope ps(c, st, PC_SOFTMAX, 0, (double)n * c->C * 8);
+        HIP_TRY(launch_softmax(dt, lg, (float *)d_probs, n, c->C, ldl, st));
+    }
+    return VITX_OK;
+}
+
+int vitx_forward(vitx_ctx *c, const float *imgs, int n, float *probs, float *logits) {
+    if (!c || !imgs || !probs) { set_error("vitx_forward: NULL argument"); return VITX_ERR_ARG; }
+    if (n <= 0 || n > c->max_batch) { set_error("vitx_forward: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t img_bytes = (size_t)n * c->S * c->S * 3 * 4;
+    HIP_TRY(hipMemcpyAsync(c->img, imgs, img_bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = vitx_forward_device(c, c->img, n, c->probs, nullptr, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(probs, c->probs, (size_t)n * c->C * 4, hipMemcpyDeviceToHost, c->stream));
+    if (logits) HIP_TRY(hipMemcpy2DAsync(logits, (size_t)c->C * 4, c->logits, (size_t)c->C_pad * 4, (size_t)c->C * 4, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VITX_OK;
+}
+
+int vitx_ctx_synchronize(vitx_ctx *c) {
+    if (!c) return VITX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VITX_OK;
+}
+
+int vitx_profile_enable(vitx_ctx *c, int on) {
+    if (!c) return VITX_ERR_ARG;
+    c->prof_on = on != 0; c->recs.clear(); c->ev_used = 0;
+    return VITX_OK;
+}
+
+int vitx_profile_read(vitx_ctx *c, vitx_prof_entry *out, int max_entries, int *n_entries) {
+    if (!c || !out || !n_entries) return VITX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    vitx_prof_entry acc[PC_COUNT];
+    for (int i = 0; i < PC_COUNT; ++i) acc[i] = vitx_prof_entry{kProfNames[i], 0, 0.0, 0.0, 0.0};
+    for (const auto &r : c->recs) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        acc[r.cls].launches++; acc[r.cls].total_ms += ms; acc[r.cls].flops += r.flops; acc[r.cls].bytes += r.bytes;
+    }
+    int k = 0;
+    for (int i = 0; i < PC_COUNT && k < max_entries; ++i) if (acc[i].launches) out[k++] = acc[i];
+    *n_entries = k;
+    c->recs.clear(); c->ev_used = 0;
+    return VITX_OK;
+}
+
+// ---- single-kernel entry points --------------------------------------------------------------
+int vitx_op_layernorm(int dtype, const void *x, const void *w, const void *b, void *y, int M, int D, float eps, void *stream) {
+    if (!x || !w || !b || !y || M <= 0) return VITX_ERR_ARG;
+    hipError_t e = launch_layernorm(dtype, (const float *)x, D, (const float *)w, (const float *)b, y, D, M, D, eps, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_op_layernorm: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
+    return VITX_OK;
+}
+int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *bias, void *out, int M, int N, int K, void *stream) {
+    if (!a || !w || !out || epi < 0 || epi > 3) return VITX_ERR_ARG;
+    if (M % gemm_tile_m() || N % 64 || K % 64) { set_error("vitx_op_gemm: M %% %d, N %% 64, K %% 64 must be 0", gemm_tile_m()); return VITX_ERR_ARG; }
+    // W (and bias) must hold N rounded up to the 128-row N tile; rows beyond N are never stored
+    GemmArgs g{};
+    g.A = a; g.W = w; g.bias = (const float *)bias; g.out = out; g.pos = nullptr;
+    g.M = M; g.M_real = M; g.N = N; g.N_pad = round_up(N, gemm_tile_n()); g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = 0;
+    hipError_t e = launch_gemm(dtype, epi, g, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_op_gemm: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
+int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
+    if (!qkv || !out || n_img <= 0) return VITX_ERR_ARG;
+    hipError_t e = launch_attention(dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_op_attention: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
+    return VITX_OK;
+}
+int vitx_op_softmax(const void *logits, void *probs, int rows, int cols, int ld, void *stream) {
+    if (!logits || !probs || rows <= 0 || cols <= 0) return VITX_ERR_ARG;
+    hipError_t e = launch_softmax(DT_F16, (const float *)logits, (float *)probs, rows, cols, ld, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_op_softmax: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
+
+}  // extern "C"

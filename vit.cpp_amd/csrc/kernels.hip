@@ -1,0 +1,498 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the ViT forward path.
+//
+// Written for MI355X only: 64-lane wavefronts, v_mfma_f32_32x32x16_{f16,bf16},
+// global_load_lds (LDS-DMA) staging with a source-side XOR swizzle, 160 KiB LDS.
+// The math each kernel implements is the ggml op sequence vit_encode_image emits
+// (/root/reference/vit.cpp:718-941); per-kernel citations below.
+#include "kernels.h"
+
+namespace vitx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+template <typename T> struct Elem;
+template <> struct Elem<_Float16> {
+    typedef half8 v8; typedef half4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Elem<__bf16> {
+    typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)(T)x; }   // round-trip through the operand type
+
+// tanh-GELU of the reference (ggml_gelu_f32): 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x))),
+// evaluated as x*sigmoid(2u) = x / (1 + exp(-2u)), algebraically identical and stable in both tails.
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS tile image shared by the GEMM and attention kernels: rows of 64 elements (128 B = 8 slots of
+// 16 B).  Two rows form one 256-B bank line; the 16 slots of a line are XOR-ed with (line & 15) so a
+// ds_read_b128 lane group (16 rows, same logical slot) touches 16 distinct slots: conflict-free.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_byte(int row, int slot /*0..7*/) {
+    const int line = row >> 1;
+    const int s16 = ((row & 1) << 3) | slot;
+    return line * 256 + ((s16 ^ (line & 15)) << 4);
+}
+// inverse: physical 16-B slot index p (within the tile) -> logical (row, slot)
+__device__ __forceinline__ void swz_inv(int p, int &row, int &slot) {
+    const int line = p >> 4;
+    const int s16 = (p & 15) ^ (line & 15);
+    row = line * 2 + (s16 >> 3);
+    slot = s16 & 7;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C[M][N] = A[M][K] . W[N][K]^T  (ggml_mul_mat, vit.cpp:820,868,889,896,927 and the im2col GEMM
+// of ggml_conv_2d_sk_p0, vit.cpp:772) with the bias / GELU / residual / pos-embed epilogues fused.
+// 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles, LDS double buffer filled
+// by global_load_lds dwordx4 (one K-tile ahead).
+// ------------------------------------------------------------------------------------------------
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int G_TILE_BYTES = GBM * GBK * 2;            // 16 KiB per operand tile
+constexpr int G_STAGE_BYTES = 2 * G_TILE_BYTES;        // A + W
+constexpr int G_LDS_BYTES = 2 * G_STAGE_BYTES;         // double buffer: 64 KiB
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    // XCD-aware tile order: blocks b, b+8, b+16, ... (same XCD, co-resident) get consecutive tile ids,
+    // which share the same A row panel (n fastest).  Bijective for any grid size.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ntn = g.N_pad / GBN;
+    const int m0 = (tile / ntn) * GBM, n0 = (tile % ntn) * GBN;
+
+    const T *A = (const T *)g.A, *W = (const T *)g.W;
+    // per-thread source offsets of the 4+4 16-byte pieces this thread DMA-loads per K tile
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, slot; swz_inv(i * 256 + tid, row, slot);
+        aoff[i] = (m0 + row) * g.lda + slot * 8;
+        woff[i] = (n0 + row) * g.ldw + slot * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        char *base = smem + buf * G_STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GPTR(A + aoff[i] + k0), LPTR(base + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GPTR(W + woff[i] + k0), LPTR(base + G_TILE_BYTES + i * 4096), 16, 0, 0);
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment read addresses: row = w*64 + i*32 + l31, slot = ks*2 + hh
+    int a_rd[2][4], w_rd[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a_rd[i][ks] = swz_byte(wm * 64 + i * 32 + l31, ks * 2 + hh);
+            w_rd[i][ks] = G_TILE_BYTES + swz_byte(wn * 64 + i * 32 + l31, ks * 2 + hh);
+        }
+
+    const int nk = g.K / GBK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * GBK);
+        const char *sb = smem + cur * G_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            typename Elem<T>::v8 af[2], wf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *(const typename Elem<T>::v8 *)(sb + a_rd[i][ks]);
+                wf[i] = *(const typename Elem<T>::v8 *)(sb + w_rd[i][ks]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mfma(af[i], wf[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue.  C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (row >= g.M_real) continue;
+                float v = acc[i][j][r] + bv;
+                if (EPI == EPI_BIAS) {
+                    ((T *)g.out)[(size_t)row * g.ldo + col] = (T)v;
+                } else if (EPI == EPI_BIAS_GELU) {
+                    ((T *)g.out)[(size_t)row * g.ldo + col] = (T)gelu_tanh(rnd<T>(v));
+                } else if (EPI == EPI_BIAS_RESID) {
+                    float *o = (float *)g.out + (size_t)row * g.ldo + col;
+                    *o = v + *o;
+                } else if (EPI == EPI_BIAS_F32) {
+                    ((float *)g.out)[(size_t)row * g.ldo + col] = v;
+                } else {   // EPI_PATCH
+                    const int b = row / g.tpi, t = row - b * g.tpi;
+                    const size_t orow = (size_t)row + b + 1;
+                    ((float *)g.out)[orow * g.ldo + col] = v + g.pos[(size_t)(t + 1) * g.ldo + col];
+                }
+            }
+        }
+    }
+}
+
+int gemm_tile_m() { return GBM; }
+int gemm_tile_n() { return GBN; }
+
+template <typename T>
+static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream) {
+    const int grid = (a.M / GBM) * (a.N_pad / GBN);
+    const dim3 blk(256);
+#define VITX_GEMM_CASE(E)                                                                                   \
+    case E: {                                                                                               \
+        static bool attr_set = false;                                                                       \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES); attr_set = true; } \
+        hipLaunchKernelGGL((gemm_nt_kernel<T, E>), dim3(grid), blk, G_LDS_BYTES, stream, a);                \
+    } break;
+    switch (epi) {
+        VITX_GEMM_CASE(EPI_BIAS)
+        VITX_GEMM_CASE(EPI_BIAS_GELU)
+        VITX_GEMM_CASE(EPI_BIAS_RESID)
+        VITX_GEMM_CASE(EPI_BIAS_F32)
+        VITX_GEMM_CASE(EPI_PATCH)
+    default: return hipErrorInvalidValue;
+    }
+#undef VITX_GEMM_CASE
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
+    if (a.M % GBM || a.N_pad % GBN || a.K % GBK || a.M <= 0) return hipErrorInvalidValue;
+    return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream) : launch_gemm_t<__bf16>(epi, a, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col (vit.cpp:759-772): out[b*g*g + t][k], k = c*P*P + ky*P + kx, token t = px + g*py, from the HWC
+// f32 image; rounded to the operand type exactly where ggml's im2col emits fp16.  8 elements (16 B)
+// per thread; columns k >= 3*P*P and rows >= n_img*g*g are zero padding.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ img, T *__restrict__ out, int n_img, int S, int P, int Kpad, int rows_pad) {
+    const int g = S / P, tpi = g * g, K = 3 * P * P, PP = P * P;
+    const int chunks_per_row = Kpad / 8;
+    const long total = (long)rows_pad * chunks_per_row;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(id / chunks_per_row), kc = (int)(id % chunks_per_row);
+        typename Elem<T>::v8 v;
+        const int b = row / tpi, t = row - b * tpi, py = t / g, px = t - py * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kc * 8 + j;
+            float x = 0.0f;
+            if (row < n_img * tpi && k < K) {
+                const int c = k / PP, rem = k - c * PP, ky = rem / P, kx = rem - ky * P;
+                x = img[(((size_t)b * S + (py * P + ky)) * S + (px * P + kx)) * 3 + c];
+            }
+            v[j] = (T)x;
+        }
+        *(typename Elem<T>::v8 *)(out + (size_t)row * Kpad + kc * 8) = v;
+    }
+}
+
+hipError_t launch_patchify(int dtype, const float *img, void *out, int n_img, int S, int P, int Kpad, int rows_pad, hipStream_t stream) {
+    const long total = (long)rows_pad * (Kpad / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dtype == DT_F16) hipLaunchKernelGGL(patchify_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, img, (_Float16 *)out, n_img, S, P, Kpad, rows_pad);
+    else hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, img, (__bf16 *)out, n_img, S, P, Kpad, rows_pad);
+    return hipGetLastError();
+}
+
+// X[b*N][:] = cls_token + pos_embed[0]   (ggml_concat + ggml_add_inplace, vit.cpp:794-797)
+__global__ void cls_rows_kernel(const float *__restrict__ cls, const float *__restrict__ pos, float *__restrict__ X, int n_img, int N, int D) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) X[(size_t)b * N * D + i] = cls[i] + pos[i];
+}
+hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_img, int N, int D, hipStream_t stream) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(n_img), dim3(256), 0, stream, cls, pos, X, n_img, N, D);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (ggml_norm + ggml_mul + ggml_add_inplace, vit.cpp:808-812, 881-885, 915-919):
+// mean, then biased variance of (x-mean), y = ((x-mean) * 1/sqrt(var+eps)) * w + b, rounded to the
+// operand type of the GEMM that consumes it.  One wave per row, row kept in registers.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ w, const float *__restrict__ b,
+                                                        T *__restrict__ y, long ldy, int M, float eps) {
+    constexpr int D = 64 * VEC * NV;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float *xr = x + (size_t)row * ldx;
+    float v[NV][VEC];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = (i * 64 + lane) * VEC;
+        if constexpr (VEC == 4) { const float4 t = *(const float4 *)(xr + idx); v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w; }
+        else if constexpr (VEC == 2) { const float2 t = *(const float2 *)(xr + idx); v[i][0] = t.x; v[i][1] = t.y; }
+        else v[i][0] = xr[idx];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sum += v[i][j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)D;
+    float sum2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { v[i][j] -= mean; sum2 += v[i][j] * v[i][j]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o);
+    const float scale = 1.0f / sqrtf(sum2 / (float)D + eps);
+    T *yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = (i * 64 + lane) * VEC;
+        T o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { float t = v[i][j] * scale; t = t * w[idx + j]; o[j] = (T)(t + b[idx + j]); }
+        if constexpr (VEC == 4) *(typename Elem<T>::v4 *)(yr + idx) = typename Elem<T>::v4{o[0], o[1], o[2], o[3]};
+        else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) yr[idx + j] = o[j];
+        }
+    }
+}
+
+template <typename T>
+static hipError_t launch_layernorm_t(const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream) {
+    const dim3 grid((M + 3) / 4), blk(256);
+#define VITX_LN_CASE(DD, VEC, NV) \
+    case DD: hipLaunchKernelGGL((layernorm_kernel<T, VEC, NV>), grid, blk, 0, stream, x, ldx, w, b, (T *)y, ldy, M, eps); break;
+    switch (D) {
+        VITX_LN_CASE(64, 1, 1) VITX_LN_CASE(128, 2, 1) VITX_LN_CASE(192, 1, 3) VITX_LN_CASE(256, 4, 1) VITX_LN_CASE(384, 2, 3)
+        VITX_LN_CASE(512, 4, 2) VITX_LN_CASE(768, 4, 3) VITX_LN_CASE(1024, 4, 4) VITX_LN_CASE(1280, 4, 5) VITX_LN_CASE(1536, 4, 6)
+    default: return hipErrorInvalidValue;
+    }
+#undef VITX_LN_CASE
+    return hipGetLastError();
+}
+hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream) {
+    return dtype == DT_F16 ? launch_layernorm_t<_Float16>(x, ldx, w, b, y, ldy, M, D, eps, stream) : launch_layernorm_t<__bf16>(x, ldx, w, b, y, ldy, M, D, eps, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused attention for one (image, head) per workgroup (vit.cpp:826-866): S = K Q^T * 1/8, softmax
+// over keys, O = P V, heads merged on store.  head_dim is 64 for every model the reference converts.
+//   * K [Nk][64] is staged in LDS in the swizzled row image above, V is staged TRANSPOSED
+//     ([64][Nk+8], keys permuted inside each group of 16 so that the MFMA k-slot order of the P
+//     registers needs no shuffle).
+//   * "swapped" products: S^T = K . Q^T puts a whole score column (one query) in one lane pair, so the
+//     softmax max/sum are in-register reductions plus one cross-half shuffle; O^T = V^T . P^T then
+//     takes the probabilities straight from the accumulator registers as its B operand.
+//   * each wave owns 32 queries; all NKT key tiles are kept in registers (single pass, no online
+//     rescale), which fits N <= 608 tokens.
+// exp follows ggml_soft_max: e = round(exp(round(s - max))) in the operand type (fp16 LUT in ggml).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NKT, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = NKT * 32;          // padded key count
+    constexpr int VLD = NK + 8;           // V^T row stride (elements); (VLD/8) odd -> conflict-free b128 reads
+    char *Ks = smem;
+    T *VT = (T *)(smem + NK * 128);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const T *base = qkv + (size_t)b * N * 3 * D + h * 64;
+
+    // ---- stage K (swizzled rows) and V^T
+    typedef typename Elem<T>::v8 v8;
+    for (int c = tid; c < NK * 8; c += NWAVES * 64) {
+        const int key = c >> 3, s = c & 7;
+        v8 kv, vv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kv[j] = (T)0.0f; vv[j] = (T)0.0f; }
+        if (key < N) {
+            kv = *(const v8 *)(base + (size_t)key * 3 * D + D + s * 8);
+            vv = *(const v8 *)(base + (size_t)key * 3 * D + 2 * D + s * 8);
+        }
+        *(v8 *)(Ks + swz_byte(key, s)) = kv;
+        const int a = key & 15;
+        const int q4 = a >> 2, q4s = (q4 == 1) ? 2 : (q4 == 2) ? 1 : q4;     // key groups 4-7 <-> 8-11 swapped
+        const int pos = (key & ~15) | (q4s << 2) | (a & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) VT[(s * 8 + j) * VLD + pos] = vv[j];
+    }
+    __syncthreads();
+
+    for (int qt = wave; qt < NKT; qt += NWAVES) {
+        int qrow = qt * 32 + l31;
+        const bool qvalid = qrow < N;
+        if (!qvalid) qrow = N - 1;
+        v8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qrow * 3 * D + ks * 16 + hh * 8);
+
+        // S^T tiles: rows = keys, cols = queries
+        f32x16 s[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v8 kf = *(const v8 *)(Ks + swz_byte(kt * 32 + l31, ks * 2 + hh));
+                s[kt] = Elem<T>::mfma(kf, qf[ks], s[kt]);
+            }
+        }
+        // scale (exact, 2^-3), mask padded keys, max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v = (key < N) ? s[kt][r] * 0.125f : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.0f;
+        v8 p[NKT][2];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = (s[kt][r] == -INFINITY) ? 0.0f : rnd<T>(__expf(rnd<T>(s[kt][r] - mx)));
+                sum += e;
+                p[kt][r >> 3][r & 7] = (T)e;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // O^T = V^T . P^T : rows = head dims (2 tiles of 32), cols = queries
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const v8 vf = *(const v8 *)(VT + (dt * 32 + l31) * VLD + kt * 32 + half * 16 + hh * 8);
+                    o[dt] = Elem<T>::mfma(vf, p[kt][half], o[dt]);
+                }
+        }
+        if (qvalid) {
+            T *orow = out + ((size_t)b * N + qrow) * D + h * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    typename Elem<T>::v4 w4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w4[j] = (T)(o[dt][r4 * 4 + j] * inv);
+                    *(typename Elem<T>::v4 *)(orow + dt * 32 + r4 * 8 + hh * 4) = w4;
+                }
+        }
+    }
+}
+
+template <typename T, int NKT, int NWAVES>
+static hipError_t launch_attention_inst(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+    constexpr int lds = NKT * 32 * 128 + 64 * (NKT * 32 + 8) * 2;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)attention_kernel<T, NKT, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+    hipLaunchKernelGGL((attention_kernel<T, NKT, NWAVES>), dim3(n_img * H), dim3(NWAVES * 64), lds, stream, (const T *)qkv, (T *)out, N, D, H);
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_attention_t(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+    const int nkt = (N + 31) / 32;
+    switch (nkt) {
+    case 1: return launch_attention_inst<T, 1, 1>(qkv, out, n_img, N, D, H, stream);
+    case 2: return launch_attention_inst<T, 2, 2>(qkv, out, n_img, N, D, H, stream);
+    case 3: return launch_attention_inst<T, 3, 3>(qkv, out, n_img, N, D, H, stream);
+    case 4: return launch_attention_inst<T, 4, 4>(qkv, out, n_img, N, D, H, stream);
+    case 5: return launch_attention_inst<T, 5, 5>(qkv, out, n_img, N, D, H, stream);
+    case 6: return launch_attention_inst<T, 6, 6>(qkv, out, n_img, N, D, H, stream);
+    case 7: return launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream);      // 197 tokens (224/16)
+    case 9: return launch_attention_inst<T, 9, 5>(qkv, out, n_img, N, D, H, stream);      // 257 tokens (224/14)
+    case 19: return launch_attention_inst<T, 19, 4>(qkv, out, n_img, N, D, H, stream);    // 577 tokens (384/16)
+    default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+    if (D != H * 64) return hipErrorInvalidValue;
+    return dtype == DT_F16 ? launch_attention_t<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(qkv, out, n_img, N, D, H, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Class softmax (ggml_soft_max, vit.cpp:931): max, e_i = round(expf(round(x_i - max))), p = e * (1/sum).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_kernel(const float *__restrict__ logits, float *__restrict__ probs, int cols, int ld) {
+    __shared__ float red[4];
+    const float *x = logits + (size_t)blockIdx.x * ld;
+    float *p = probs + (size_t)blockIdx.x * cols;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float mx = -INFINITY;
+    for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, x[i]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.0f;
+    for (int i = tid; i < cols; i += 256) { const float e = rnd<T>(expf(rnd<T>(x[i] - mx))); p[i] = e; sum += e; }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int i = tid; i < cols; i += 256) p[i] *= inv;
+}
+hipError_t launch_softmax(int dtype, const float *logits, float *probs, int rows, int cols, int ld, hipStream_t stream) {
+    if (dtype == DT_F16) hipLaunchKernelGGL(softmax_kernel<_Float16>, dim3(rows), dim3(256), 0, stream, logits, probs, cols, ld);
+    else hipLaunchKernelGGL(softmax_kernel<__bf16>, dim3(rows), dim3(256), 0, stream, logits, probs, cols, ld);
+    return hipGetLastError();
+}
+
+}  // namespace vitx
