@@ -89,7 +89,8 @@ def test_gemm_transpose_detecting(binding, torch_gpu):
     w = (np.arange(N)[:, None] * 0.5 + np.arange(K)[None, :] * 0.001953125).astype(np.float16)
     out = torch.zeros((M, N), dtype=torch.float32, device="cuda")
     zb = torch.zeros(N, dtype=torch.float32, device="cuda")
-    binding.check(binding.lib().vitx_op_gemm(binding.F16, 3, _dev(torch, a).data_ptr(), _dev(torch, w).data_ptr(), zb.data_ptr(), out.data_ptr(), M, N, K, None))
+    da, dw = _dev(torch, a), _dev(torch, w)      # keep the device tensors alive across the launch
+    binding.check(binding.lib().vitx_op_gemm(binding.F16, 3, da.data_ptr(), dw.data_ptr(), zb.data_ptr(), out.data_ptr(), M, N, K, None))
     _sync(torch)
     ref = a.astype(np.float32) @ w.astype(np.float32).T
     assert np.array_equal(out.cpu().numpy(), ref)
@@ -123,7 +124,8 @@ def test_attention_forced_spike(binding, oracle, torch_gpu):
     qkv[10, :64] = 4.0; qkv[150, 64:128] = 4.0          # q10 . k150 = 1024 -> *0.125 = 128
     ref = oracle.attention(qkv.astype(np.float32), n_img, N, D, H, oracle.REF)
     out = torch.zeros((N, D), dtype=torch.float16, device="cuda")
-    binding.check(binding.lib().vitx_op_attention(binding.F16, _dev(torch, qkv).data_ptr(), out.data_ptr(), n_img, N, D, H, None))
+    dq = _dev(torch, qkv)
+    binding.check(binding.lib().vitx_op_attention(binding.F16, dq.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
     _sync(torch)
     got = out.float().cpu().numpy()
     assert np.isfinite(got).all()
@@ -137,7 +139,8 @@ def test_softmax_matches_ggml_lut(binding, oracle, torch_gpu):
     x = (rng.standard_normal((37, 1000)) * 4).astype(np.float32)
     ref = oracle.softmax_rows(x, lut=1)
     out = torch.zeros((37, 1000), dtype=torch.float32, device="cuda")
-    binding.check(binding.lib().vitx_op_softmax(_dev(torch, x).data_ptr(), out.data_ptr(), 37, 1000, 1000, None))
+    dx = _dev(torch, x)
+    binding.check(binding.lib().vitx_op_softmax(dx.data_ptr(), out.data_ptr(), 37, 1000, 1000, None))
     _sync(torch)
     got = out.cpu().numpy()
     assert np.abs(got - ref).max() <= 2e-6

@@ -1,0 +1,54 @@
+// device_common.h -- types and helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vitx {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+template <typename T> struct Elem;
+template <> struct Elem<_Float16> {
+    typedef half8 v8; typedef half4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Elem<__bf16> {
+    typedef bf16x8 v8; typedef bf16x4 v4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)(T)x; }   // round-trip through the operand type
+
+// tanh-GELU of the reference (ggml_gelu_f32): 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x))),
+// evaluated as x*sigmoid(2u) = x / (1 + exp(-2u)), algebraically identical and stable in both tails.
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS tile image shared by the GEMM and attention kernels: rows of 64 elements (128 B = 8 slots of
+// 16 B).  Two rows form one 256-B bank line; the 16 slots of a line are XOR-ed with (line & 15) so a
+// ds_read_b128 lane group (16 rows, same logical slot) touches 16 distinct slots: conflict-free.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_byte(int row, int slot /*0..7*/) {
+    const int line = row >> 1;
+    const int s16 = ((row & 1) << 3) | slot;
+    return line * 256 + ((s16 ^ (line & 15)) << 4);
+}
+// inverse: physical 16-B slot index p (within the tile) -> logical (row, slot)
+__device__ __forceinline__ void swz_inv(int p, int &row, int &slot) {
+    const int line = p >> 4;
+    const int s16 = (p & 15) ^ (line & 15);
+    row = line * 2 + (s16 >> 3);
+    slot = s16 & 7;
+}
+
+
+}  // namespace vitx

@@ -333,7 +333,7 @@ int vitx_op_layernorm(int dtype, const void *x, const void *w, const void *b, vo
 }
 int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *bias, void *out, int M, int N, int K, void *stream) {
     if (!a || !w || !out || epi < 0 || epi > 3) return VITX_ERR_ARG;
-    if (M % gemm_tile_m() || N % 64 || K % 64) { set_error("vitx_op_gemm: M %% %d, N %% 64, K %% 64 must be 0", gemm_tile_m()); return VITX_ERR_ARG; }
+    if (M % 128 || N % 64 || K % 64) { set_error("vitx_op_gemm: M %% 128, N %% 64, K %% 64 must be 0"); return VITX_ERR_ARG; }
     // W (and bias) must hold N rounded up to the 128-row N tile; rows beyond N are never stored
     GemmArgs g{};
     g.A = a; g.W = w; g.bias = (const float *)bias; g.out = out; g.pos = nullptr;

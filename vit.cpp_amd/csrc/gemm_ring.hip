@@ -1,0 +1,312 @@
+// gemm_ring.hip -- the main MFMA GEMM of the ViT forward path for gfx950.
+//
+//   C[M][N] = A[M][K] . W[N][K]^T   (+ fused epilogue), A/W fp16 or bf16, f32 accumulate.
+//
+// Design (MI355X-first, see DESIGN.md "GEMM"):
+//   * waves are laid out 2(M) x NWN(N); each wave owns (WMT*32) x 64 of C as WMT x 2 MFMA 32x32x16
+//     accumulators.  Two geometries are instantiated:
+//       - "wide":  8 waves, tile 256x256, one workgroup per CU (ring of 4-5 slots, 128-160 KiB LDS);
+//       - "pair":  4 waves, tile 256x128, TWO workgroups per CU (ring of 3 slots, 72 KiB LDS each), so
+//         that one workgroup's barrier / prologue / epilogue is covered by the other's MFMAs.
+//   * K is consumed in slots of 32: an LDS ring of NS slots, each [A: BM x 32 | W: BN x 32] halves.
+//     Slots are filled by LDS-DMA (global_load_lds dwordx4) issued NS-1 slots ahead and retired with
+//     COUNTED s_waitcnt vmcnt(N) + one raw s_barrier per slot, so loads stay in flight across
+//     barriers (the compiler's __syncthreads() would drain them).
+//   * fragment registers are double buffered across 16-deep k-steps: the ds_read_b128 of step j+1
+//     (possibly in the next, already-landed slot) are issued under the MFMAs of step j.
+//   * 64-byte LDS rows, 4 rows per 256-B bank line, 16-B slots XOR-ed with (line & 15): every
+//     ds_read_b128 lane group hits 16 distinct slots (conflict-free); the LDS image itself is
+//     lane-linear (DMA requirement), the permutation is applied to the per-lane global source address.
+//   * workgroup -> tile map: XCD-contiguous ids, then GROUP_M x n blocks so the tiles co-resident on
+//     one XCD share A and W panels in that XCD's 4 MiB L2.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace vitx {
+
+constexpr int GROUP_M = 8;          // m-tiles per raster group
+
+__device__ __forceinline__ int swz64_byte(int row, int s /*0..3*/) {
+    const int line = row >> 2;
+    const int s16 = ((row & 3) << 2) | s;
+    return line * 256 + ((s16 ^ (line & 15)) << 4);
+}
+__device__ __forceinline__ void swz64_inv(int p, int &row, int &s) {
+    const int line = p >> 4;
+    const int s16 = (p & 15) ^ (line & 15);
+    row = line * 4 + (s16 >> 2);
+    s = s16 & 3;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// Fused epilogue of one wave's (WMT*32) x 64 accumulator block.  FULL tiles skip every bounds check.
+// C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <typename T, int EPI, int WMT, bool FULL>
+__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][2], int row0, int col0) {
+    float bv[2]; bool col_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { col_ok[j] = FULL || (col0 + j * 32) < g.N; bv[j] = col_ok[j] ? g.bias[col0 + j * 32] : 0.0f; }
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+        if constexpr (EPI == EPI_BIAS_RESID) {
+            // read-modify-write of the f32 residual stream: all 32 loads of this 32-row block first
+            float res[2][16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = FULL || (col_ok[j] && row < g.M_real);
+                    res[j][r] = ok ? ((const float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] : 0.0f;
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (!FULL && !(col_ok[j] && row < g.M_real)) continue;
+                    ((float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] = (acc[i][j][r] + bv[j]) + res[j][r];
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = col0 + j * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (!FULL && !(col_ok[j] && row < g.M_real)) continue;
+                    const float v = acc[i][j][r] + bv[j];
+                    if constexpr (EPI == EPI_BIAS) {
+                        ((T *)g.out)[(size_t)row * g.ldo + col] = (T)v;
+                    } else if constexpr (EPI == EPI_BIAS_GELU) {
+                        ((T *)g.out)[(size_t)row * g.ldo + col] = (T)gelu_tanh(rnd<T>(v));
+                    } else if constexpr (EPI == EPI_BIAS_F32) {
+                        ((float *)g.out)[(size_t)row * g.ldo + col] = v;
+                    } else {   // EPI_PATCH
+                        const int b = row / g.tpi, t = row - b * g.tpi;
+                        ((float *)g.out)[((size_t)row + b + 1) * g.ldo + col] = v + g.pos[(size_t)(t + 1) * g.ldo + col];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int EPI, int WMT, int NWN, int NS, int KS, bool DBG>
+__global__ __launch_bounds__(NWN * 128, 2) void gemm_ring_kernel(GemmArgs g) {
+    constexpr int RBK = 16 * KS;                    // K per ring slot (KS k-steps of 16): 32 -> 64-B rows, 64 -> 128-B rows
+    constexpr int ROWB = 2 * RBK;
+    constexpr int NT = NWN * 128;                   // threads: 2 x NWN waves
+    constexpr int BM = WMT * 64, BN = NWN * 64;
+    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, SLOT_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_PIECES = BM * (ROWB / 16) / NT; // 16-B pieces per thread per slot
+    constexpr int W_PIECES = BN * (ROWB / 16) / NT;
+    constexpr int G = A_PIECES + W_PIECES;          // LDS-DMA instructions per thread per slot
+    constexpr int PIECE_STRIDE = NT * 16;           // LDS bytes covered by one workgroup-wide DMA instruction
+    typedef typename Elem<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int dbg = DBG ? g.dbg : 0;
+
+    // ---- workgroup -> tile
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int ntm = g.M / BM, ntn = g.N_pad / BN;
+    const int per_group = GROUP_M * ntn;
+    const int grp = lid / per_group, within = lid - grp * per_group;
+    const int gm = min(GROUP_M, ntm - grp * GROUP_M);
+    const int tn = within / gm, tmi = grp * GROUP_M + (within - tn * gm);
+    const int m0 = tmi * BM, n0 = tn * BN;
+
+    // ---- per-thread DMA source offsets (elements) and wave-uniform LDS destinations
+    const T *A = (const T *)g.A, *W = (const T *)g.W;
+    int aoff[A_PIECES], woff[W_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) { int row, s; if (KS == 2) swz64_inv(i * NT + tid, row, s); else swz_inv(i * NT + tid, row, s); aoff[i] = (m0 + row) * g.lda + s * 8; }
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) { int row, s; if (KS == 2) swz64_inv(i * NT + tid, row, s); else swz_inv(i * NT + tid, row, s); woff[i] = (n0 + row) * g.ldw + s * 8; }
+    auto issue = [&](int slot, int pos) {
+        char *base = smem + pos * SLOT_BYTES + wave * 1024;
+        const int k0 = slot * RBK;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) __builtin_amdgcn_global_load_lds(GPTR(A + aoff[i] + k0), LPTR(base + i * PIECE_STRIDE), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_PIECES; ++i) __builtin_amdgcn_global_load_lds(GPTR(W + woff[i] + k0), LPTR(base + A_BYTES + i * PIECE_STRIDE), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets within a slot: row = wave base + tile*32 + l31, 16-B slot = ks*2 + hh
+    int a_rd[WMT][KS], w_rd[2][KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) { const int r = wm * (WMT * 32) + i * 32 + l31; a_rd[i][ks] = KS == 2 ? swz64_byte(r, ks * 2 + hh) : swz_byte(r, ks * 2 + hh); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + l31; w_rd[j][ks] = A_BYTES + (KS == 2 ? swz64_byte(r, ks * 2 + hh) : swz_byte(r, ks * 2 + hh)); }
+    }
+
+    f32x16 acc[WMT][2];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nslots = g.K / RBK;
+    // ---- prologue: NS-1 slots in flight, slots 0 and 1 landed
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) if (s < nslots) issue(s, s);
+    {
+        const int keep = max(0, min(NS - 1, nslots) - 2);      // slots allowed to stay in flight
+        if (NS == 2) wait_vmcnt<0>();
+        else if (NS > 3 && keep >= NS - 3) wait_vmcnt<(NS > 3 ? NS - 3 : 0) * G>(); else if (NS > 4 && keep == 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+    }
+    wg_barrier();
+
+    v8 fa[2][WMT], fw[2][2];
+    auto load_frags = [&](int buf, int pos, int ks) {
+        const char *sb = smem + pos * SLOT_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[buf][j] = *(const v8 *)(sb + w_rd[j][ks]);
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) fa[buf][i] = *(const v8 *)(sb + a_rd[i][ks]);
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mfma(fa[buf][i], fw[buf][j], acc[i][j]);
+    };
+    if (NS > 2) load_frags(0, 0, 0);
+
+    long long t_cyc = 0, t_real = 0;
+    if (DBG && (dbg & 32)) { t_cyc = __builtin_readcyclecounter(); t_real = wall_clock64(); }
+    if (DBG && (dbg & 2)) load_frags(1, 0, 1);
+    int pos = 0;                                    // ring position of slot i
+    for (int i = 0; i < nslots; ++i) {
+        const int pos_next = (pos + 1 == NS) ? 0 : pos + 1;
+        const int pos_fill = (pos == 0) ? NS - 1 : pos - 1;     // = (i + NS - 1) % NS, freed by the barrier that ended iteration i-1
+        if (i + NS - 1 < nslots && !(dbg & 1)) issue(i + NS - 1, pos_fill);
+        if (NS == 2 && !(dbg & 2)) load_frags(0, pos, 0);                      // double buffer: the slot only became visible at the barrier
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (!(dbg & 2)) {
+                if (ks + 1 < KS) load_frags((ks + 1) & 1, pos, ks + 1);
+                else if (NS > 2 && i + 1 < nslots) load_frags((ks + 1) & 1, pos_next, 0);   // slot i+1 landed one iteration ago
+            }
+            if (!(dbg & 4)) mma(ks & 1);
+        }
+        // slot i+2 must have landed before the next iteration's prefetch of it; later slots stay in flight
+        if (!(dbg & 16)) {
+            const int keep = min(i + NS - 1, nslots - 1) - (i + 2);            // slots allowed in flight (may be < 0)
+            if (NS == 2) wait_vmcnt<0>();
+            else if (NS > 3 && keep >= NS - 3) wait_vmcnt<(NS > 3 ? NS - 3 : 0) * G>();
+            else if (NS > 4 && keep == 1) wait_vmcnt<G>();
+            else wait_vmcnt<0>();
+            wg_barrier();
+        }
+        pos = pos_next;
+    }
+
+    if (DBG && (dbg & 8)) {          // experiments: keep the accumulators and fragments alive, store nothing
+        if (dbg & 4) { asm volatile("" ::"v"(fa[0][0]), "v"(fa[1][0]), "v"(fw[0][0]), "v"(fw[1][0])); }
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][15];
+        if (s == 1234.5678f) ((float *)g.out)[0] = s;
+        if ((dbg & 32) && tid == 0) {   // per-block timeline: K-loop start/end on the 100 MHz wall clock, shader cycles
+            long long *d = (long long *)g.pos + (size_t)bid * 4;
+            d[0] = t_real; d[1] = wall_clock64(); d[2] = __builtin_readcyclecounter() - t_cyc; d[3] = xcd;
+        }
+        return;
+    }
+    const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
+    if (full) epilogue<T, EPI, WMT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * 64 + l31);
+    else epilogue<T, EPI, WMT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * 64 + l31);
+}
+
+// ---- configurations: cfg = WMT*100 + NWN*10 + NS
+struct RingCfg { int wmt, nwn, ns, ks; };
+static bool parse_cfg(int cfg, RingCfg &c) {
+    c.ks = cfg >= 1000 ? cfg / 1000 : 2; cfg %= 1000;
+    c.wmt = cfg / 100; c.nwn = (cfg / 10) % 10; c.ns = cfg % 10;
+    return (c.ks == 2 && (cfg == 445 || cfg == 423 || cfg == 245)) || (c.ks == 4 && (cfg == 442 || cfg == 243));
+}
+
+template <typename T, int EPI, int WMT, int NWN, int NS, int KS, bool DBG>
+static hipError_t launch_ring_inst(const GemmArgs &a, hipStream_t stream) {
+    constexpr int BM = WMT * 64, BN = NWN * 64;
+    constexpr int lds = NS * (BM + BN) * 32 * KS;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<T, EPI, WMT, NWN, NS, KS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+    const int grid = (a.M / BM) * (a.N_pad / BN);
+    hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, WMT, NWN, NS, KS, DBG>), dim3(grid), dim3(NWN * 128), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename T, int EPI, bool DBG>
+static hipError_t launch_ring_e(const GemmArgs &a, int cfg, hipStream_t stream) {
+    switch (cfg) {
+    case 445: return launch_ring_inst<T, EPI, 4, 4, 5, 2, DBG>(a, stream);
+    case 423: return launch_ring_inst<T, EPI, 4, 2, 3, 2, DBG>(a, stream);
+    case 245: return launch_ring_inst<T, EPI, 2, 4, 5, 2, DBG>(a, stream);
+    case 4442: return launch_ring_inst<T, EPI, 4, 4, 2, 4, DBG>(a, stream);     // BK = 64 double buffer, 128-B rows
+    case 4243: return launch_ring_inst<T, EPI, 2, 4, 3, 4, DBG>(a, stream);     // 128x256 tile, BK = 64, 3 slots (144 KiB)
+    default: return hipErrorInvalidValue;
+    }
+}
+template <typename T>
+static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, hipStream_t stream) {
+    if (a.dbg) return epi == EPI_BIAS ? launch_ring_e<T, EPI_BIAS, true>(a, cfg, stream) : hipErrorInvalidValue;
+    switch (epi) {
+    case EPI_BIAS: return launch_ring_e<T, EPI_BIAS, false>(a, cfg, stream);
+    case EPI_BIAS_GELU: return launch_ring_e<T, EPI_BIAS_GELU, false>(a, cfg, stream);
+    case EPI_BIAS_RESID: return launch_ring_e<T, EPI_BIAS_RESID, false>(a, cfg, stream);
+    case EPI_BIAS_F32: return launch_ring_e<T, EPI_BIAS_F32, false>(a, cfg, stream);
+    case EPI_PATCH: return launch_ring_e<T, EPI_PATCH, false>(a, cfg, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+bool gemm_ring_supports(const GemmArgs &a, int cfg) {
+    RingCfg c;
+    if (!parse_cfg(cfg, c)) return false;
+    return a.M % (c.wmt * 64) == 0 && a.N_pad % (c.nwn * 64) == 0 && a.K % (16 * c.ks) == 0 && a.K >= 32 * c.ks;
+}
+
+hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a0, int cfg, hipStream_t stream) {
+    if (!gemm_ring_supports(a0, cfg)) return hipErrorInvalidValue;
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("VITX_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    GemmArgs a = a0; a.dbg = dbg;
+    if (dbg & 32) {      // experiment mode: collect and print a per-block timeline (synchronous)
+        RingCfg c; parse_cfg(cfg, c);
+        const int nwg = (a.M / (c.wmt * 64)) * (a.N_pad / (c.nwn * 64));
+        long long *buf = nullptr;
+        if (hipHostMalloc((void **)&buf, (size_t)nwg * 32, 0) != hipSuccess) return hipErrorOutOfMemory;
+        a.pos = (const float *)buf;
+        hipError_t e = dtype == DT_F16 ? launch_ring_t<_Float16>(a, epi, cfg, stream) : launch_ring_t<__bf16>(a, epi, cfg, stream);
+        (void)hipDeviceSynchronize();
+        long long t0 = buf[0], t1 = 0; double sum = 0, sumc = 0;
+        for (int b = 0; b < nwg; ++b) { t0 = std::min(t0, buf[b * 4]); t1 = std::max(t1, buf[b * 4 + 1]); sum += buf[b * 4 + 1] - buf[b * 4]; sumc += buf[b * 4 + 2]; }
+        fprintf(stderr, "[ring dbg] cfg %d: %d blocks, span %.1f us, mean K-loop %.1f us (%.0f shader cycles, %.0f MHz)\n", cfg, nwg, (t1 - t0) / 100.0, sum / nwg / 100.0, sumc / nwg, sumc / sum * 100.0);
+        (void)hipHostFree(buf);
+        return e;
+    }
+    return dtype == DT_F16 ? launch_ring_t<_Float16>(a, epi, cfg, stream) : launch_ring_t<__bf16>(a, epi, cfg, stream);
+}
+
+}  // namespace vitx

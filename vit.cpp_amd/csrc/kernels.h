@@ -26,6 +26,7 @@ struct GemmArgs {
     int K;        // multiple of 64
     int lda, ldw, ldo;
     int tpi;      // EPI_PATCH: patch tokens per image (g*g)
+    int dbg;      // ablation bits for kernel experiments (VITX_GEMM_DBG): 1 no DMA in loop, 2 no ds_read in loop, 4 no MFMA, 8 no epilogue
 };
 
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream);

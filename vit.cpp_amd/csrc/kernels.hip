@@ -4,55 +4,13 @@
 // global_load_lds (LDS-DMA) staging with a source-side XOR swizzle, 160 KiB LDS.
 // The math each kernel implements is the ggml op sequence vit_encode_image emits
 // (/root/reference/vit.cpp:718-941); per-kernel citations below.
+#include <stdlib.h>
+#include <string.h>
+
 #include "kernels.h"
+#include "device_common.h"
 
 namespace vitx {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
-#define LPTR(p) ((__attribute__((address_space(3))) void *)(p))
-
-template <typename T> struct Elem;
-template <> struct Elem<_Float16> {
-    typedef half8 v8; typedef half4 v4;
-    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-};
-template <> struct Elem<__bf16> {
-    typedef bf16x8 v8; typedef bf16x4 v4;
-    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
-template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)(T)x; }   // round-trip through the operand type
-
-// tanh-GELU of the reference (ggml_gelu_f32): 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x))),
-// evaluated as x*sigmoid(2u) = x / (1 + exp(-2u)), algebraically identical and stable in both tails.
-__device__ __forceinline__ float gelu_tanh(float x) {
-    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS tile image shared by the GEMM and attention kernels: rows of 64 elements (128 B = 8 slots of
-// 16 B).  Two rows form one 256-B bank line; the 16 slots of a line are XOR-ed with (line & 15) so a
-// ds_read_b128 lane group (16 rows, same logical slot) touches 16 distinct slots: conflict-free.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int swz_byte(int row, int slot /*0..7*/) {
-    const int line = row >> 1;
-    const int s16 = ((row & 1) << 3) | slot;
-    return line * 256 + ((s16 ^ (line & 15)) << 4);
-}
-// inverse: physical 16-B slot index p (within the tile) -> logical (row, slot)
-__device__ __forceinline__ void swz_inv(int p, int &row, int &slot) {
-    const int line = p >> 4;
-    const int s16 = (p & 15) ^ (line & 15);
-    row = line * 2 + (s16 >> 3);
-    slot = s16 & 7;
-}
 
 // ------------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] . W[N][K]^T  (ggml_mul_mat, vit.cpp:820,868,889,896,927 and the im2col GEMM
@@ -174,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
-int gemm_tile_m() { return GBM; }
+int gemm_tile_m() { return 256; }   // row padding of every activation buffer (ring kernel tile height)
 int gemm_tile_n() { return GBN; }
 
 template <typename T>
@@ -199,8 +157,37 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream) 
     return hipGetLastError();
 }
 
+bool gemm_ring_supports(const GemmArgs &a, int cfg);
+hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream);
+bool gemm_pers_supports(const GemmArgs &a);
+hipError_t launch_gemm_pers(int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream);
+
+// Kernel selection.  VITX_GEMM_CFG overrides it for experiments: "v1" (128x128 two-stage kernel) or
+// WMT*100+NWN*10+NS of the ring kernel ("445": 256x256 tile 8 waves 5-slot ring; "423": 256x128 tile, 4 waves, 3 slots, 2 WG/CU).
+static int gemm_cfg_override() {
+    static int cfg = -2;
+    if (cfg == -2) {
+        const char *e = getenv("VITX_GEMM_CFG");
+        cfg = !e ? -1 : (!strcmp(e, "v1") ? 0 : atoi(e));
+    }
+    return cfg;
+}
+
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
-    if (a.M % GBM || a.N_pad % GBN || a.K % GBK || a.M <= 0) return hipErrorInvalidValue;
+    if (a.M <= 0) return hipErrorInvalidValue;
+    int cfg = gemm_cfg_override();
+    if (cfg < 0) {
+        // 256x256 tiles (8 waves, 5-slot ring) whenever the shape allows and there is at least a wave of tiles;
+        // 128x256 tiles for short M (e.g. the classifier head) -- measured in profiles/r01_gemm_configs.txt
+        const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
+        cfg = (a.M % 256 == 0 && t256 >= 128) ? 445 : 245;
+    }
+    if (cfg >= 900) {
+        if (gemm_pers_supports(a)) return launch_gemm_pers(dtype, epi, a, cfg, stream);
+        cfg = 245;
+    }
+    if (cfg > 0 && gemm_ring_supports(a, cfg)) return launch_gemm_ring(dtype, epi, a, cfg, stream);
+    if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
     return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream) : launch_gemm_t<__bf16>(epi, a, stream);
 }
 
