@@ -48,16 +48,17 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "mem
 
 // Fused epilogue of one wave's (WMT*32) x 64 accumulator block.  FULL tiles skip every bounds check.
 // C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <typename T, int EPI, int WMT, bool FULL>
-__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][2], int row0, int col0) {
-    float bv[2]; bool col_ok[2];
+template <typename T, int EPI, int WMT, int WNT, bool FULL>
+__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][WNT], int row0, int col0) {
+    float bv[WNT]; bool col_ok[WNT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { col_ok[j] = FULL || (col0 + j * 32) < g.N; bv[j] = col_ok[j] ? g.bias[col0 + j * 32] : 0.0f; }
+    for (int j = 0; j < WNT; ++j) { col_ok[j] = FULL || (col0 + j * 32) < g.N; bv[j] = col_ok[j] ? g.bias[col0 + j * 32] : 0.0f; }
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         if constexpr (EPI == EPI_BIAS_RESID) {
             // read-modify-write of the f32 residual stream: all 32 loads of this 32-row block first
             float res[2][16];
+            static_assert(EPI != EPI_BIAS_RESID || WNT == 2, "RMW epilogue batches two column tiles");
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -76,7 +77,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][2
                 }
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < WNT; ++j) {
                 const int col = col0 + j * 32;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -99,12 +100,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][2
     }
 }
 
-template <typename T, int EPI, int WMT, int NWN, int NS, int KS, bool DBG>
-__global__ __launch_bounds__(NWN * 128, 2) void gemm_ring_kernel(GemmArgs g) {
+template <typename T, int EPI, int WMT, int WNT, int NWM, int NWN, int NS, int KS, bool DBG>
+__global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ? 1 : (NWM * NWN * 64) / 256) void gemm_ring_kernel(GemmArgs g) {
     constexpr int RBK = 16 * KS;                    // K per ring slot (KS k-steps of 16): 32 -> 64-B rows, 64 -> 128-B rows
     constexpr int ROWB = 2 * RBK;
-    constexpr int NT = NWN * 128;                   // threads: 2 x NWN waves
-    constexpr int BM = WMT * 64, BN = NWN * 64;
+    constexpr int NT = NWM * NWN * 64;              // threads: NWM x NWN waves
+    constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32;
     constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, SLOT_BYTES = A_BYTES + W_BYTES;
     constexpr int A_PIECES = BM * (ROWB / 16) / NT; // 16-B pieces per thread per slot
     constexpr int W_PIECES = BN * (ROWB / 16) / NT;
@@ -146,20 +147,20 @@ __global__ __launch_bounds__(NWN * 128, 2) void gemm_ring_kernel(GemmArgs g) {
     };
 
     // ---- fragment read offsets within a slot: row = wave base + tile*32 + l31, 16-B slot = ks*2 + hh
-    int a_rd[WMT][KS], w_rd[2][KS];
+    int a_rd[WMT][KS], w_rd[WNT][KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int i = 0; i < WMT; ++i) { const int r = wm * (WMT * 32) + i * 32 + l31; a_rd[i][ks] = KS == 2 ? swz64_byte(r, ks * 2 + hh) : swz_byte(r, ks * 2 + hh); }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + l31; w_rd[j][ks] = A_BYTES + (KS == 2 ? swz64_byte(r, ks * 2 + hh) : swz_byte(r, ks * 2 + hh)); }
+        for (int j = 0; j < WNT; ++j) { const int r = wn * (WNT * 32) + j * 32 + l31; w_rd[j][ks] = A_BYTES + (KS == 2 ? swz64_byte(r, ks * 2 + hh) : swz_byte(r, ks * 2 + hh)); }
     }
 
-    f32x16 acc[WMT][2];
+    f32x16 acc[WMT][WNT];
 #pragma unroll
     for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WNT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -174,11 +175,11 @@ __global__ __launch_bounds__(NWN * 128, 2) void gemm_ring_kernel(GemmArgs g) {
     }
     wg_barrier();
 
-    v8 fa[2][WMT], fw[2][2];
+    v8 fa[2][WMT], fw[2][WNT];
     auto load_frags = [&](int buf, int pos, int ks) {
         const char *sb = smem + pos * SLOT_BYTES;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fw[buf][j] = *(const v8 *)(sb + w_rd[j][ks]);
+        for (int j = 0; j < WNT; ++j) fw[buf][j] = *(const v8 *)(sb + w_rd[j][ks]);
 #pragma unroll
         for (int i = 0; i < WMT; ++i) fa[buf][i] = *(const v8 *)(sb + a_rd[i][ks]);
     };
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(NWN * 128, 2) void gemm_ring_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mfma(fa[buf][i], fw[buf][j], acc[i][j]);
+            for (int j = 0; j < WNT; ++j) acc[i][j] = Elem<T>::mfma(fa[buf][i], fw[buf][j], acc[i][j]);
     };
     if (NS > 2) load_frags(0, 0, 0);
 
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(NWN * 128, 2) void gemm_ring_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][15];
+            for (int j = 0; j < WNT; ++j) s += acc[i][j][0] + acc[i][j][15];
         if (s == 1234.5678f) ((float *)g.out)[0] = s;
         if ((dbg & 32) && tid == 0) {   // per-block timeline: K-loop start/end on the 100 MHz wall clock, shader cycles
             long long *d = (long long *)g.pos + (size_t)bid * 4;
@@ -234,37 +235,38 @@ __global__ __launch_bounds__(NWN * 128, 2) void gemm_ring_kernel(GemmArgs g) {
         return;
     }
     const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
-    if (full) epilogue<T, EPI, WMT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * 64 + l31);
-    else epilogue<T, EPI, WMT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * 64 + l31);
+    if (full) epilogue<T, EPI, WMT, WNT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31);
+    else epilogue<T, EPI, WMT, WNT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31);
 }
 
 // ---- configurations: cfg = WMT*100 + NWN*10 + NS
-struct RingCfg { int wmt, nwn, ns, ks; };
+struct RingCfg { int wmt, nwn, ns, ks, wnt, nwm; };
 static bool parse_cfg(int cfg, RingCfg &c) {
     c.ks = cfg >= 1000 ? cfg / 1000 : 2; cfg %= 1000;
     c.wmt = cfg / 100; c.nwn = (cfg / 10) % 10; c.ns = cfg % 10;
-    return (c.ks == 2 && (cfg == 445 || cfg == 423 || cfg == 245)) || (c.ks == 4 && (cfg == 442 || cfg == 243));
+    c.wnt = 2; c.nwm = 2;
+    if (c.ks == 2 && (cfg == 165 || cfg == 164)) { c.wmt = 2; c.nwm = 4; c.nwn = 4; return true; }
+    return c.ks == 2 && (cfg == 445 || cfg == 245);
 }
 
-template <typename T, int EPI, int WMT, int NWN, int NS, int KS, bool DBG>
+template <typename T, int EPI, int WMT, int WNT, int NWM, int NWN, int NS, int KS, bool DBG>
 static hipError_t launch_ring_inst(const GemmArgs &a, hipStream_t stream) {
-    constexpr int BM = WMT * 64, BN = NWN * 64;
+    constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32;
     constexpr int lds = NS * (BM + BN) * 32 * KS;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<T, EPI, WMT, NWN, NS, KS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
     const int grid = (a.M / BM) * (a.N_pad / BN);
-    hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, WMT, NWN, NS, KS, DBG>), dim3(grid), dim3(NWN * 128), lds, stream, a);
+    hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS, DBG>), dim3(grid), dim3(NWM * NWN * 64), lds, stream, a);
     return hipGetLastError();
 }
 
 template <typename T, int EPI, bool DBG>
 static hipError_t launch_ring_e(const GemmArgs &a, int cfg, hipStream_t stream) {
     switch (cfg) {
-    case 445: return launch_ring_inst<T, EPI, 4, 4, 5, 2, DBG>(a, stream);
-    case 423: return launch_ring_inst<T, EPI, 4, 2, 3, 2, DBG>(a, stream);
-    case 245: return launch_ring_inst<T, EPI, 2, 4, 5, 2, DBG>(a, stream);
-    case 4442: return launch_ring_inst<T, EPI, 4, 4, 2, 4, DBG>(a, stream);     // BK = 64 double buffer, 128-B rows
-    case 4243: return launch_ring_inst<T, EPI, 2, 4, 3, 4, DBG>(a, stream);     // 128x256 tile, BK = 64, 3 slots (144 KiB)
+    case 445: return launch_ring_inst<T, EPI, 4, 2, 2, 4, 5, 2, DBG>(a, stream);
+    case 245: return launch_ring_inst<T, EPI, 2, 2, 2, 4, 5, 2, DBG>(a, stream);
+    case 165: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 5, 2, DBG>(a, stream);      // 16 waves (4 per SIMD), 64x64 per wave, tile 256x256
+    case 164: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 4, 2, DBG>(a, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -284,7 +286,7 @@ static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, hipStream_t
 bool gemm_ring_supports(const GemmArgs &a, int cfg) {
     RingCfg c;
     if (!parse_cfg(cfg, c)) return false;
-    return a.M % (c.wmt * 64) == 0 && a.N_pad % (c.nwn * 64) == 0 && a.K % (16 * c.ks) == 0 && a.K >= 32 * c.ks;
+    return a.M % (c.nwm * c.wmt * 32) == 0 && a.N_pad % (c.nwn * c.wnt * 32) == 0 && a.K % (16 * c.ks) == 0 && a.K >= 32 * c.ks;
 }
 
 hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a0, int cfg, hipStream_t stream) {
@@ -294,7 +296,7 @@ hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a0, int cfg, hip
     GemmArgs a = a0; a.dbg = dbg;
     if (dbg & 32) {      // experiment mode: collect and print a per-block timeline (synchronous)
         RingCfg c; parse_cfg(cfg, c);
-        const int nwg = (a.M / (c.wmt * 64)) * (a.N_pad / (c.nwn * 64));
+        const int nwg = (a.M / (c.nwm * c.wmt * 32)) * (a.N_pad / (c.nwn * c.wnt * 32));
         long long *buf = nullptr;
         if (hipHostMalloc((void **)&buf, (size_t)nwg * 32, 0) != hipSuccess) return hipErrorOutOfMemory;
         a.pos = (const float *)buf;

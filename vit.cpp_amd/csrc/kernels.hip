@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 #include "device_common.h"
 
@@ -186,6 +188,31 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream
         if (gemm_pers_supports(a)) return launch_gemm_pers(dtype, epi, a, cfg, stream);
         cfg = 245;
     }
+    // Tail split: one 256x256 tile per CU per round means e.g. 591 tiles (N = 768) cost 3 rounds for 2.31 rounds of
+    // work.  Rows that fill whole rounds keep 256x256 tiles; the remaining rows are re-tiled 128x256 (half-cost tiles)
+    // in a second launch, which turns a 0.3-round remainder into ~0.35 rounds instead of a full one.
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    if (cfg == 445 && gemm_cfg_override() < 0 && epi != EPI_PATCH && gemm_ring_supports(a, 445) && getenv("VITX_GEMM_SPLIT") != nullptr) {   // opt-in: A/B runs were within noise
+        const int ntm = a.M / 256, ntn = a.N_pad / 256;
+        const long tiles = (long)ntm * ntn, rounds = tiles / n_cu, rem = tiles % n_cu;
+        if (rounds >= 1 && rem > 0 && rem <= n_cu * 6 / 10) {
+            const int m_main = (int)((rounds * n_cu) / ntn);                 // m-tiles that fit in whole rounds
+            const int rows_main = m_main * 256;
+            if (m_main >= 1 && rows_main < a.M) {
+                GemmArgs head = a, tail = a;
+                head.M = rows_main; head.M_real = std::min(a.M_real, rows_main);
+                const size_t esz_out = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? 2 : 4;
+                tail.A = (const char *)a.A + (size_t)rows_main * a.lda * 2;
+                tail.out = (char *)a.out + (size_t)rows_main * a.ldo * esz_out;
+                tail.M = a.M - rows_main; tail.M_real = a.M_real - rows_main;
+                hipError_t e = launch_gemm_ring(dtype, epi, head, 445, stream);
+                if (e != hipSuccess) return e;
+                if (tail.M_real <= 0) return hipSuccess;
+                return launch_gemm_ring(dtype, epi, tail, 245, stream);
+            }
+        }
+    }
     if (cfg > 0 && gemm_ring_supports(a, cfg)) return launch_gemm_ring(dtype, epi, a, cfg, stream);
     if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
     return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream) : launch_gemm_t<__bf16>(epi, a, stream);
@@ -318,8 +345,9 @@ hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w,
 // exp follows ggml_soft_max: e = round(exp(round(s - max))) in the operand type (fp16 LUT in ggml).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NKT, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H) {
+__global__ __launch_bounds__(NWAVES * 64, (NKT <= 7 && NWAVES <= 4) ? 2 : 1) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = NWAVES * 64;
     constexpr int NK = NKT * 32;          // padded key count
     constexpr int VLD = NK + 8;           // V^T row stride (elements); (VLD/8) odd -> conflict-free b128 reads
     char *Ks = smem;
@@ -328,27 +356,53 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_kernel(const T *__restr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const T *base = qkv + (size_t)b * N * 3 * D + h * 64;
-
-    // ---- stage K (swizzled rows) and V^T
     typedef typename Elem<T>::v8 v8;
-    for (int c = tid; c < NK * 8; c += NWAVES * 64) {
-        const int key = c >> 3, s = c & 7;
-        v8 kv, vv;
+
+    // ---- stage K: 16-B pieces in row order (coalesced 128-B rows), all loads issued before the LDS writes
+    {
+        constexpr int IT = (NK * 8 + NT - 1) / NT;
+        v8 kv[IT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kv[j] = (T)0.0f; vv[j] = (T)0.0f; }
-        if (key < N) {
-            kv = *(const v8 *)(base + (size_t)key * 3 * D + D + s * 8);
-            vv = *(const v8 *)(base + (size_t)key * 3 * D + 2 * D + s * 8);
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid, key = c >> 3, sl = c & 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kv[it][j] = (T)0.0f;
+            if (c < NK * 8 && key < N) kv[it] = *(const v8 *)(base + (size_t)key * 3 * D + D + sl * 8);
         }
-        *(v8 *)(Ks + swz_byte(key, s)) = kv;
-        const int a = key & 15;
-        const int q4 = a >> 2, q4s = (q4 == 1) ? 2 : (q4 == 2) ? 1 : q4;     // key groups 4-7 <-> 8-11 swapped
-        const int pos = (key & ~15) | (q4s << 2) | (a & 3);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) VT[(s * 8 + j) * VLD + pos] = vv[j];
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid;
+            if (c < NK * 8) *(v8 *)(Ks + swz_byte(c >> 3, c & 7)) = kv[it];
+        }
+    }
+    // ---- stage V^T: one work item = (key pair, 8 head dims).  Consecutive lanes take consecutive key pairs, so
+    // each of the 8 transposed stores is a 4-byte (two keys) write to consecutive dwords of one V^T row (no bank
+    // conflicts); keys 4-7 <-> 8-11 of every 16 are swapped (MFMA k-slot order of the P registers).
+    {
+        constexpr int NP = NK / 2, ITEMS = NP * 8, IT = (ITEMS + NT - 1) / NT;
+        v8 va[IT], vb[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid, pr = c % NP, sl = c / NP, key = 2 * pr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { va[it][j] = (T)0.0f; vb[it][j] = (T)0.0f; }
+            if (c < ITEMS && key < N) va[it] = *(const v8 *)(base + (size_t)key * 3 * D + 2 * D + sl * 8);
+            if (c < ITEMS && key + 1 < N) vb[it] = *(const v8 *)(base + (size_t)(key + 1) * 3 * D + 2 * D + sl * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid, pr = c % NP, sl = c / NP, key = 2 * pr;
+            if (c >= ITEMS) continue;
+            const int a = key & 15, q4 = a >> 2, q4s = (q4 == 1) ? 2 : (q4 == 2) ? 1 : q4;
+            const int pos = (key & ~15) | (q4s << 2) | (a & 3);
+            typedef T v2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(v2 *)(VT + (sl * 8 + j) * VLD + pos) = v2{va[it][j], vb[it][j]};
+        }
     }
     __syncthreads();
 
+#pragma unroll 1
     for (int qt = wave; qt < NKT; qt += NWAVES) {
         int qrow = qt * 32 + l31;
         const bool qvalid = qrow < N;
@@ -375,8 +429,11 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_kernel(const T *__restr
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float v = (key < N) ? s[kt][r] * 0.125f : -INFINITY;
+                float v = s[kt][r] * 0.125f;
+                if (kt == NKT - 1) {       // only the last key tile can hold padded keys
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= N) v = -INFINITY;
+                }
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -387,7 +444,8 @@ __global__ __launch_bounds__(NWAVES * 64) void attention_kernel(const T *__restr
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = (s[kt][r] == -INFINITY) ? 0.0f : rnd<T>(__expf(rnd<T>(s[kt][r] - mx)));
+                float e = rnd<T>(__expf(rnd<T>(s[kt][r] - mx)));
+                if (kt == NKT - 1 && s[kt][r] == -INFINITY) e = 0.0f;
                 sum += e;
                 p[kt][r >> 3][r & 7] = (T)e;
             }
@@ -439,10 +497,14 @@ static hipError_t launch_attention_t(const void *qkv, void *out, int n_img, int 
     case 2: return launch_attention_inst<T, 2, 2>(qkv, out, n_img, N, D, H, stream);
     case 3: return launch_attention_inst<T, 3, 3>(qkv, out, n_img, N, D, H, stream);
     case 4: return launch_attention_inst<T, 4, 4>(qkv, out, n_img, N, D, H, stream);
-    case 5: return launch_attention_inst<T, 5, 5>(qkv, out, n_img, N, D, H, stream);
-    case 6: return launch_attention_inst<T, 6, 6>(qkv, out, n_img, N, D, H, stream);
-    case 7: return launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream);      // 197 tokens (224/16)
-    case 9: return launch_attention_inst<T, 9, 5>(qkv, out, n_img, N, D, H, stream);      // 257 tokens (224/14)
+    case 5: return launch_attention_inst<T, 5, 4>(qkv, out, n_img, N, D, H, stream);
+    case 6: return launch_attention_inst<T, 6, 4>(qkv, out, n_img, N, D, H, stream);
+    case 7: {                                                                             // 197 tokens (224/16)
+        static int w = -1;
+        if (w < 0) { const char *e = getenv("VITX_ATTN_WAVES"); w = e ? atoi(e) : 7; }
+        return w == 4 ? launch_attention_inst<T, 7, 4>(qkv, out, n_img, N, D, H, stream) : launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream);
+    }
+    case 9: return launch_attention_inst<T, 9, 4>(qkv, out, n_img, N, D, H, stream);      // 257 tokens (224/14)
     case 19: return launch_attention_inst<T, 19, 4>(qkv, out, n_img, N, D, H, stream);    // 577 tokens (384/16)
     default: return hipErrorInvalidValue;
     }
