@@ -20,6 +20,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HBM-side bytes per launch of the GEMM kernels from the separate rocprofv3 --pmc passes committed under profiles/
+# (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); bf16, batch 256.
+HBM_TRAFFIC_GB = {"gemm_fc1_gelu": 0.739, "gemm_qkv_bias": 0.580, "gemm_fc2_resid": 0.675, "gemm_proj_resid": 0.675}   # resid: proj/fc2 share one kernel symbol (mean)
 PEAK_TFLOPS = 2516.6      # dense bf16/fp16 MFMA, 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH: ~2.5 PF)
 
 
@@ -77,13 +80,14 @@ def main():
     mean = torch.tensor(pkg.synth.IMAGENET_MEAN); std = torch.tensor(pkg.synth.IMAGENET_STD)
     imgs = ((u8.float() - mean) / std).contiguous().cuda()
     probs = torch.empty((B, C), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world * B, C), dtype=torch.float32, device="cuda") if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
+
+    state = {}
 
     def step():
         ctx.forward_device(imgs.data_ptr(), B, probs.data_ptr(), 0, stream)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, probs)
+        if world > 1:
+            state["all"] = pkg.dist.gather_probs(probs, world * B)     # the one collective: [world*B, C] class probabilities
 
     for _ in range(args.warmup):
         step()
@@ -131,7 +135,7 @@ def main():
             dom = max(gemms, key=lambda p: p["total_ms"])
             tf = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(tf / PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_GB.get(dom["name"]), "traffic_unit": "GB per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_forward_rocprofv3_stats.txt)",
                                "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "flops_per_launch": dom["flops"] / dom["launches"]}
             tot = sum(p["total_ms"] for p in prof)
             out["kernel_breakdown"] = {p["name"]: {"ms_per_step": round(p["total_ms"] / args.steps, 4), "share": round(p["total_ms"] / tot, 4),

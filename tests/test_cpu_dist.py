@@ -1,0 +1,69 @@
+"""The N>1 path on CPU: two processes over gloo run the same shard -> forward -> all-gather
+plumbing bench.py uses on RCCL (vit.cpp_amd/dist.py).  The forward itself is GPU-only, so the
+per-rank forward here is a deterministic stand-in (a function of the image content) -- what
+is under test is the sharding arithmetic and that the gathered block is in global image order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _fake_forward(block):
+    """Stand-in for the HIP engine: per-image 'probabilities' that identify the image."""
+    import torch
+    m = block.reshape(block.shape[0], -1).mean(1, keepdim=True)
+    logits = m * torch.arange(1, 8, dtype=torch.float32)[None, :]
+    return torch.softmax(logits, 1)
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import _pkg
+    pkg = _pkg.load()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    images = torch.rand((n_total, 8, 8, 3), generator=g)
+    got = pkg.dist.predict_sharded(_fake_forward, images)
+    want = _fake_forward(images)
+    ok = torch.allclose(got, want) and got.shape == want.shape
+    lo, hi = pkg.dist.shard_bounds(n_total, world, rank)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([int(ok), lo, hi]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7, 2])
+def test_two_rank_shard_and_gather(tmp_path, n_total):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, str(tmp_path))) for r in range(2)]
+    for p in procs: p.start()
+    for p in procs: p.join(120)
+    for p in procs:
+        assert p.exitcode == 0
+    res = [np.load(tmp_path / f"r{r}.npy") for r in range(2)]
+    assert all(r[0] == 1 for r in res)
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n_total      # contiguous cover
+
+
+def test_shard_bounds_cover_and_balance(pkg):
+    for n in (0, 1, 5, 256, 2048, 2049):
+        for w in (1, 2, 3, 8):
+            b = [pkg.dist.shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pkg.dist.shard_bounds(4, 2, 2)
