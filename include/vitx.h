@@ -84,7 +84,9 @@ int vitx_preprocess_u8(const uint8_t *hwc, int nx, int ny, int img_size, int int
 
 /* ---- execution context (replaces vit_state + the per-call graph build) ------ */
 /* Uploads the weights to `device` in `dtype` and allocates all activation scratch
- * for up to max_batch images once (the reference reallocates per call, vit.cpp:1009-1035). */
+ * for up to max_batch images once (the reference reallocates per call, vit.cpp:1009-1035).
+ * Contexts for >= 16 images cut every batch into 2 contiguous sub-batches that run on two
+ * internal HIP streams (env VITX_STREAMS=1..4 overrides); results do not depend on it. */
 int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out);
 void vitx_ctx_free(vitx_ctx *c);
 int vitx_ctx_max_batch(const vitx_ctx *c);
@@ -106,8 +108,9 @@ int vitx_topk(const float *probs, int num_classes, int k, int32_t *out_idx, floa
 
 /* ---- measurement ------------------------------------------------------------ */
 /* When enabled, every kernel launch of vitx_forward_device is bracketed by HIP
- * events on the launch stream; vitx_profile_read() synchronises, folds the event
- * pairs into per-kernel-class totals and clears the pool. */
+ * events on the launch stream and the sub-batches run back to back on that one
+ * stream (exclusive per-kernel durations); vitx_profile_read() synchronises, folds
+ * the event pairs into per-kernel-class totals and clears the pool. */
 #define VITX_PROF_MAX_CLASSES 16
 typedef struct vitx_prof_entry {
     const char *name;     /* kernel class, e.g. "gemm_fc1_gelu" */
@@ -115,6 +118,8 @@ typedef struct vitx_prof_entry {
     double total_ms;
     double flops;         /* algorithmic 2*M*N*K summed over the launches (0 for non-GEMM classes) */
     double bytes;         /* algorithmic HBM bytes summed over the launches */
+    double busy_ms;       /* wall time during which >= 1 launch of this class was running (union over the
+                             context's concurrent sub-batch streams); == total_ms on a single stream */
 } vitx_prof_entry;
 int vitx_profile_enable(vitx_ctx *c, int on);
 int vitx_profile_read(vitx_ctx *c, vitx_prof_entry *out, int max_entries, int *n_entries);

@@ -34,7 +34,7 @@ class HParams(C.Structure):
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("name", C.c_char_p), ("launches", C.c_int32), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int32), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("busy_ms", C.c_double)]
 
 
 class VitxError(RuntimeError):
@@ -176,7 +176,7 @@ class Context:
     def profile_read(self):
         arr = (ProfEntry * 16)(); n = C.c_int()
         check(lib().vitx_profile_read(self._h, arr, 16, C.byref(n)), "vitx_profile_read")
-        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes) for i in range(n.value)]
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes, busy_ms=arr[i].busy_ms) for i in range(n.value)]
 
 
 def topk(probs_row: np.ndarray, k: int = 5):

@@ -8,6 +8,7 @@
 // launches of a forward are enqueued on one HIP stream without host synchronisation.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -57,17 +58,29 @@ struct vitx_ctx {
     float *cls = nullptr, *pos = nullptr, *pe_b = nullptr, *norm_w = nullptr, *norm_b = nullptr, *head_b = nullptr;
     void *pe_w = nullptr, *head_w = nullptr;
     std::vector<LayerW> layers;
-    // activations
+    // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
+    // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
+    // (measured +10 % images/s at batch 256, tools/two_stream_probe.py).  Sub-batches are independent images.
+    struct Slice {
+        int cap = 0;                 // images this slice can hold
+        float *X = nullptr;          // [Mpad][D] f32 residual stream
+        void *U = nullptr;           // [Mpad][D] LN output / attention output
+        void *QKV = nullptr;         // [Mpad][3D]
+        void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
+        void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
+        float *logits = nullptr;     // [Bpad][C_pad]
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    int nslices = 1;
+    std::vector<Slice> slices;
+    hipEvent_t fork = nullptr;
     float *img = nullptr;        // [max_batch][S][S][3] staging for the host entry point
-    float *X = nullptr;          // [Mpad][D] f32 residual stream
-    void *U = nullptr;           // [Mpad][D] LN output / attention output
-    void *QKV = nullptr;         // [Mpad][3D]
-    void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
-    void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
-    float *logits = nullptr;     // [Bpad][C_pad]
     float *probs = nullptr;      // [max_batch][C]
+    float *logits_all = nullptr; // [max_batch][C] staging for the host entry point
     // profiling
     bool prof_on = false;
+    hipEvent_t prof_base = nullptr;
     struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> ev_pool;
@@ -76,6 +89,9 @@ struct vitx_ctx {
     ~vitx_ctx() {
         (void)hipSetDevice(device);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
+        for (auto &sl : slices) { if (sl.stream) (void)hipStreamDestroy(sl.stream); if (sl.done) (void)hipEventDestroy(sl.done); }
+        if (fork) (void)hipEventDestroy(fork);
+        if (prof_base) (void)hipEventDestroy(prof_base);
         for (void *p : allocs) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -200,16 +216,34 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     if ((rc = upload_f32(c.get(), T("head.bias"), &c->head_b, c->C_pad))) return rc;
     if ((rc = upload_matrix(c.get(), T("head.weight"), c->C, D, c->C_pad, D, &c->head_w))) return rc;
 
-    const size_t Mpad = (size_t)round_up(max_batch * c->N, c->tm), Bpad = (size_t)round_up(max_batch, c->tm);
+    // sub-batch slices (VITX_STREAMS overrides; 1 = single stream).  Small contexts stay single-slice.
+    int ns = 2;
+    if (const char *e = getenv("VITX_STREAMS")) ns = atoi(e);
+    if (ns < 1) ns = 1;
+    if (ns > 4) ns = 4;
+    if (max_batch < 8 * ns) ns = 1;
+    c->nslices = ns;
+    c->slices.resize(ns);
     const size_t hcols = std::max<size_t>((size_t)4 * D, (size_t)c->Kpe_pad);
+    for (int i = 0; i < ns; ++i) {
+        vitx_ctx::Slice &sl = c->slices[i];
+        sl.cap = (max_batch + ns - 1) / ns;
+        const size_t Mpad = (size_t)round_up(sl.cap * c->N, c->tm), Bpad = (size_t)round_up(sl.cap, c->tm);
+        if ((rc = c->dmalloc((void **)&sl.X, Mpad * D * 4, true))) return rc;
+        if ((rc = c->dmalloc(&sl.U, Mpad * D * 2, true))) return rc;
+        if ((rc = c->dmalloc(&sl.QKV, Mpad * 3 * D * 2, true))) return rc;
+        if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
+        if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
+        if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
+        if (ns > 1) {
+            HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
+    }
+    if (ns > 1) HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
     if ((rc = c->dmalloc((void **)&c->img, (size_t)max_batch * c->S * c->S * 3 * 4, false))) return rc;
-    if ((rc = c->dmalloc((void **)&c->X, Mpad * D * 4, true))) return rc;
-    if ((rc = c->dmalloc(&c->U, Mpad * D * 2, true))) return rc;
-    if ((rc = c->dmalloc(&c->QKV, Mpad * 3 * D * 2, true))) return rc;
-    if ((rc = c->dmalloc(&c->Hbuf, Mpad * hcols * 2, true))) return rc;
-    if ((rc = c->dmalloc(&c->Z, Bpad * D * 2, true))) return rc;
-    if ((rc = c->dmalloc((void **)&c->logits, Bpad * c->C_pad * 4, true))) return rc;
     if ((rc = c->dmalloc((void **)&c->probs, (size_t)max_batch * c->C * 4, true))) return rc;
+    if ((rc = c->dmalloc((void **)&c->logits_all, (size_t)max_batch * c->C * 4, true))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     *out = c.release();
     return VITX_OK;
@@ -218,11 +252,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
 void vitx_ctx_free(vitx_ctx *c) { delete c; }
 int vitx_ctx_max_batch(const vitx_ctx *c) { return c ? c->max_batch : 0; }
 
-int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, void *stream) {
-    if (!c || !d_imgs || !d_probs) { set_error("vitx_forward_device: NULL argument"); return VITX_ERR_ARG; }
-    if (n <= 0 || n > c->max_batch) { set_error("vitx_forward_device: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const void *d_imgs, int n, void *d_probs, void *d_logits) {
     const int D = c->D, N = c->N, tm = c->tm, tn = c->tn, dt = c->dtype;
     const int tpi = c->g * c->g;
     const int Mp_real = n * tpi, Mp = round_up(Mp_real, tm);       // patch rows
@@ -232,49 +262,89 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     // patch embedding: im2col -> GEMM(+bias, +pos, token scatter) ; cls rows      (vit.cpp:747-797)
     {
         ProfScope ps(c, st, PC_PATCHIFY, 0, (double)n * c->S * c->S * 3 * 4 + (double)Mp_real * c->Kpe_pad * eb);
-        HIP_TRY(launch_patchify(dt, (const float *)d_imgs, c->Hbuf, n, c->S, c->P, c->Kpe_pad, Mp, st));
+        HIP_TRY(launch_patchify(dt, (const float *)d_imgs, sl.Hbuf, n, c->S, c->P, c->Kpe_pad, Mp, st));
     }
     int rc;
-    if ((rc = gemm(c, st, PC_GEMM_PATCH, EPI_PATCH, c->Hbuf, c->pe_w, c->pe_b, c->X, c->pos, Mp, Mp_real, D, round_up(D, tn), c->Kpe_pad,
+    if ((rc = gemm(c, st, PC_GEMM_PATCH, EPI_PATCH, sl.Hbuf, c->pe_w, c->pe_b, sl.X, c->pos, Mp, Mp_real, D, round_up(D, tn), c->Kpe_pad,
                    c->Kpe_pad, c->Kpe_pad, D, tpi, 4))) return rc;
     {
         ProfScope ps(c, st, PC_CLS, 0, (double)n * D * 4);
-        HIP_TRY(launch_cls_rows(c->cls, c->pos, c->X, n, N, D, st));
+        HIP_TRY(launch_cls_rows(c->cls, c->pos, sl.X, n, N, D, st));
     }
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
         {   // norm1 (vit.cpp:808-812)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
-            HIP_TRY(launch_layernorm(dt, c->X, D, w.ln1_w, w.ln1_b, c->U, D, M_real, D, c->hp.eps, st));
+            HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // qkv projection (vit.cpp:820-821)
-        if ((rc = gemm(c, st, PC_GEMM_QKV, EPI_BIAS, c->U, w.qkv_w, w.qkv_b, c->QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2))) return rc;
+        if ((rc = gemm(c, st, PC_GEMM_QKV, EPI_BIAS, sl.U, w.qkv_w, w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
-            HIP_TRY(launch_attention(dt, c->QKV, c->U, n, N, D, c->H, st));
+            HIP_TRY(launch_attention(dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873)
-        if ((rc = gemm(c, st, PC_GEMM_PROJ, EPI_BIAS_RESID, c->U, w.proj_w, w.proj_b, c->X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4))) return rc;
+        if ((rc = gemm(c, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, w.proj_w, w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4))) return rc;
         {   // norm2 (vit.cpp:881-885)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
-            HIP_TRY(launch_layernorm(dt, c->X, D, w.ln2_w, w.ln2_b, c->U, D, M_real, D, c->hp.eps, st));
+            HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // MLP (vit.cpp:889-900)
-        if ((rc = gemm(c, st, PC_GEMM_FC1, EPI_BIAS_GELU, c->U, w.fc1_w, w.fc1_b, c->Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2))) return rc;
-        if ((rc = gemm(c, st, PC_GEMM_FC2, EPI_BIAS_RESID, c->Hbuf, w.fc2_w, w.fc2_b, c->X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4))) return rc;
+        if ((rc = gemm(c, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, w.fc1_w, w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2))) return rc;
+        if ((rc = gemm(c, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, w.fc2_w, w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D
     {
         ProfScope ps(c, st, PC_LAYERNORM, 0, (double)n * D * (4 + eb));
-        HIP_TRY(launch_layernorm(dt, c->X, (long)N * D, c->norm_w, c->norm_b, c->Z, D, n, D, c->hp.eps, st));
+        HIP_TRY(launch_layernorm(dt, sl.X, (long)N * D, c->norm_w, c->norm_b, sl.Z, D, n, D, c->hp.eps, st));
     }
     // classifier (vit.cpp:927-928) and class softmax (vit.cpp:931-933)
-    float *lg = d_logits ? (float *)d_logits : c->logits;
+    float *lg = d_logits ? (float *)d_logits : sl.logits;
     const int ldl = d_logits ? c->C : c->C_pad;
-    if ((rc = gemm(c, st, PC_GEMM_HEAD, EPI_BIAS_F32, c->Z, c->head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4))) return rc;
+    if ((rc = gemm(c, st, PC_GEMM_HEAD, EPI_BIAS_F32, sl.Z, c->head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4))) return rc;
     {
         ProfScope ps(c, st, PC_SOFTMAX, 0, (double)n * c->C * 8);
         HIP_TRY(launch_softmax(dt, lg, (float *)d_probs, n, c->C, ldl, st));
+    }
+    return VITX_OK;
+}
+
+int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, void *stream) {
+    if (!c || !d_imgs || !d_probs) { set_error("vitx_forward_device: NULL argument"); return VITX_ERR_ARG; }
+    if (n <= 0 || n > c->max_batch) { set_error("vitx_forward_device: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    // while per-kernel profiling is on, sub-batches run back to back on the caller's stream so that every
+    // event pair brackets one kernel running alone (exclusive durations, comparable with rocprofv3 --stats)
+    static const bool serial_env = getenv("VITX_SLICES_SERIAL") != nullptr;     // for rocprofv3 runs that should match the profiled steps
+    const int ns = (c->nslices > 1 && n >= 8 * c->nslices && !c->prof_on && !serial_env) ? c->nslices : 1;
+    if (ns == 1) {
+        if (n > c->slices[0].cap) {     // a multi-slice context asked for a small-but-too-big single slice: run the slices back to back
+            int off = 0, rc;
+            for (int i = 0; i < c->nslices && off < n; ++i) {
+                const int m = std::min(c->slices[i].cap, n - off);
+                if ((rc = forward_slice(c, c->slices[i], st, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, m, (float *)d_probs + (size_t)off * c->C,
+                                        d_logits ? (float *)d_logits + (size_t)off * c->C : nullptr))) return rc;
+                off += m;
+            }
+            return VITX_OK;
+        }
+        return forward_slice(c, c->slices[0], st, d_imgs, n, d_probs, d_logits);
+    }
+    // fork: every slice stream waits for the caller's stream, runs its contiguous sub-batch, and the caller's stream joins
+    HIP_TRY(hipEventRecord(c->fork, st));
+    const int base = n / ns, extra = n % ns;
+    int off = 0;
+    for (int i = 0; i < ns; ++i) {
+        vitx_ctx::Slice &sl = c->slices[i];
+        const int m = base + (i < extra ? 1 : 0);
+        HIP_TRY(hipStreamWaitEvent(sl.stream, c->fork, 0));
+        int rc = forward_slice(c, sl, sl.stream, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, m, (float *)d_probs + (size_t)off * c->C,
+                               d_logits ? (float *)d_logits + (size_t)off * c->C : nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(sl.done, sl.stream));
+        HIP_TRY(hipStreamWaitEvent(st, sl.done, 0));
+        off += m;
     }
     return VITX_OK;
 }
@@ -285,10 +355,10 @@ int vitx_forward(vitx_ctx *c, const float *imgs, int n, float *probs, float *log
     HIP_TRY(hipSetDevice(c->device));
     const size_t img_bytes = (size_t)n * c->S * c->S * 3 * 4;
     HIP_TRY(hipMemcpyAsync(c->img, imgs, img_bytes, hipMemcpyHostToDevice, c->stream));
-    int rc = vitx_forward_device(c, c->img, n, c->probs, nullptr, c->stream);
+    int rc = vitx_forward_device(c, c->img, n, c->probs, logits ? c->logits_all : nullptr, c->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(probs, c->probs, (size_t)n * c->C * 4, hipMemcpyDeviceToHost, c->stream));
-    if (logits) HIP_TRY(hipMemcpy2DAsync(logits, (size_t)c->C * 4, c->logits, (size_t)c->C_pad * 4, (size_t)c->C * 4, n, hipMemcpyDeviceToHost, c->stream));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, c->logits_all, (size_t)n * c->C * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VITX_OK;
 }
@@ -302,7 +372,14 @@ int vitx_ctx_synchronize(vitx_ctx *c) {
 
 int vitx_profile_enable(vitx_ctx *c, int on) {
     if (!c) return VITX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
     c->prof_on = on != 0; c->recs.clear(); c->ev_used = 0;
+    if (on) {       // time origin for the busy-interval union (kernels of concurrent slices overlap)
+        if (!c->prof_base) HIP_TRY(hipEventCreate(&c->prof_base));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipEventRecord(c->prof_base, c->stream));
+        HIP_TRY(hipEventSynchronize(c->prof_base));
+    }
     return VITX_OK;
 }
 
@@ -311,11 +388,23 @@ int vitx_profile_read(vitx_ctx *c, vitx_prof_entry *out, int max_entries, int *n
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
     vitx_prof_entry acc[PC_COUNT];
-    for (int i = 0; i < PC_COUNT; ++i) acc[i] = vitx_prof_entry{kProfNames[i], 0, 0.0, 0.0, 0.0};
+    std::vector<std::pair<float, float>> iv[PC_COUNT];
+    for (int i = 0; i < PC_COUNT; ++i) acc[i] = vitx_prof_entry{kProfNames[i], 0, 0.0, 0.0, 0.0, 0.0};
     for (const auto &r : c->recs) {
-        float ms = 0.0f;
+        float ms = 0.0f, ta = 0.0f, tb = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        if (c->prof_base) { HIP_TRY(hipEventElapsedTime(&ta, c->prof_base, r.a)); HIP_TRY(hipEventElapsedTime(&tb, c->prof_base, r.b)); iv[r.cls].push_back({ta, tb}); }
         acc[r.cls].launches++; acc[r.cls].total_ms += ms; acc[r.cls].flops += r.flops; acc[r.cls].bytes += r.bytes;
+    }
+    for (int i = 0; i < PC_COUNT; ++i) {        // union of this class's [start, stop] intervals over all streams
+        std::sort(iv[i].begin(), iv[i].end());
+        double busy = 0.0; float cur_a = 0, cur_b = -1;
+        for (auto &p : iv[i]) {
+            if (cur_b < cur_a || p.first > cur_b) { if (cur_b >= cur_a) busy += cur_b - cur_a; cur_a = p.first; cur_b = p.second; }
+            else cur_b = std::max(cur_b, p.second);
+        }
+        if (cur_b >= cur_a && !iv[i].empty()) busy += cur_b - cur_a;
+        acc[i].busy_ms = iv[i].empty() ? acc[i].total_ms : busy;
     }
     int k = 0;
     for (int i = 0; i < PC_COUNT && k < max_entries; ++i) if (acc[i].launches) out[k++] = acc[i];
