@@ -94,6 +94,27 @@ def test_batch_independence_and_padding(pkg, binding, torch_gpu):
     assert np.array_equal(all5, again)      # deterministic
 
 
+def test_large_batch_kernels_agree_with_small_batch_kernels(pkg, binding, torch_gpu):
+    """ViT-B/16 at batch 203 (ragged: 2 sub-batches of 102/101 images, 256x256 persistent-stream GEMM tiles with a
+    partial last row tile + the 128x256 tail launch) must reproduce what the small-batch kernels (128x256 tiles, one
+    stream) compute for the same images: every kernel consumes K in the same order, so the result is bit-identical."""
+    name = "vit_base_patch16_224"
+    path = pkg.synth.cached_synthetic(name, head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(203, 224, seed=5))
+    model = binding.Model(path)
+    for dt in (binding.F16, binding.BF16):
+        big = binding.Context(model, max_batch=203, dtype=dt)
+        p_big, l_big = big.forward(imgs, want_logits=True)
+        big.close()
+        small = binding.Context(model, max_batch=4, dtype=dt)
+        idx = [0, 1, 2, 3, 100, 101, 102, 103, 199, 200, 201, 202]
+        p_small = np.concatenate([small.forward(imgs[i:i + 4]) for i in (0, 100, 199)])
+        small.close()
+        assert np.isfinite(p_big).all() and np.abs(p_big.sum(1) - 1).max() < 1e-4
+        assert np.array_equal(p_big[idx], p_small)
+    model.close()
+
+
 def test_errors_are_loud(pkg, binding, torch_gpu):
     path = pkg.synth.cached_synthetic("vit_micro_patch16_64", head_scale=4.0)
     model = binding.Model(path)

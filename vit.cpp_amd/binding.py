@@ -14,7 +14,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitx.so")
+LIB_PATH = os.environ.get("VITX_LIB") or os.path.join(_HERE, "libvitx.so")   # VITX_LIB: development override (A/B builds)
 
 F16, BF16 = 0, 1
 BICUBIC, BILINEAR = 0, 1

@@ -27,6 +27,9 @@
 #include "device_common.h"
 #include "kernels.h"
 
+#ifndef RING_SCHED
+#define RING_SCHED 1
+#endif
 namespace vitx {
 
 constexpr int GROUP_M = 8;          // m-tiles per raster group
@@ -46,13 +49,20 @@ __device__ __forceinline__ void swz64_inv(int p, int &row, int &s) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+// Bias of the wave's WNT column tiles (this lane's column of each), 0 beyond N.
+template <int WNT>
+__device__ __forceinline__ void load_bias(const GemmArgs &g, int col0, float (&bv)[WNT]) {
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) { const int c = col0 + j * 32; bv[j] = c < g.N ? g.bias[c] : 0.0f; }
+}
+
 // Fused epilogue of one wave's (WMT*32) x 64 accumulator block.  FULL tiles skip every bounds check.
 // C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <typename T, int EPI, int WMT, int WNT, bool FULL>
-__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][WNT], int row0, int col0) {
-    float bv[WNT]; bool col_ok[WNT];
+__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][WNT], int row0, int col0, const float (&bv)[WNT]) {
+    bool col_ok[WNT];
 #pragma unroll
-    for (int j = 0; j < WNT; ++j) { col_ok[j] = FULL || (col0 + j * 32) < g.N; bv[j] = col_ok[j] ? g.bias[col0 + j * 32] : 0.0f; }
+    for (int j = 0; j < WNT; ++j) col_ok[j] = FULL || (col0 + j * 32) < g.N;
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         if constexpr (EPI == EPI_BIAS_RESID) {
@@ -204,9 +214,20 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
         for (int ks = 0; ks < KS; ++ks) {
             if (!(dbg & 2)) {
                 if (ks + 1 < KS) load_frags((ks + 1) & 1, pos, ks + 1);
+#if RING_SCHED
+                else if (NS > 2) load_frags((ks + 1) & 1, pos_next, 0);                     // unconditional: keeps the k-step one scheduling region (stale data past the end is never used)
+#else
                 else if (NS > 2 && i + 1 < nslots) load_frags((ks + 1) & 1, pos_next, 0);   // slot i+1 landed one iteration ago
+#endif
             }
             if (!(dbg & 4)) mma(ks & 1);
+#if RING_SCHED
+            // MFMA first (its operands were read during the previous k-step), then one LDS read per MFMA
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+            for (int q = 0; q < (WMT + WNT) / RING_SCHED; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, RING_SCHED, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, WMT * WNT - 1 - (WMT + WNT) / RING_SCHED, 0);
+#endif
         }
         // slot i+2 must have landed before the next iteration's prefetch of it; later slots stay in flight
         if (!(dbg & 16)) {
@@ -235,8 +256,154 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
         return;
     }
     const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
-    if (full) epilogue<T, EPI, WMT, WNT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31);
-    else epilogue<T, EPI, WMT, WNT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31);
+    float bv[WNT];
+    load_bias<WNT>(g, n0 + wn * (WNT * 32) + l31, bv);
+    if (full) epilogue<T, EPI, WMT, WNT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
+    else epilogue<T, EPI, WMT, WNT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
+}
+
+// ---- persistent variant: one workgroup per CU walks tiles v = bid, bid + grid, ... and keeps ONE ring running
+// across tile boundaries: the slots of the next tile are already in flight (and its first fragments in registers)
+// while the epilogue of the current tile stores, so neither the launch gap nor the cold prologue of a fresh
+// workgroup is paid per tile (measured 6.6 us of 27 us per 256x256x768 tile in the one-tile-per-workgroup kernel).
+// vmcnt counts the epilogue's stores as well as the DMA loads; loads retire in order among themselves, so a
+// counted wait stays correct (only stricter) while stores are outstanding.  To keep the stores off the critical
+// path every slot in flight is drained BEFORE the epilogue (they are 1-4 slots old) and the first two slots of
+// the next tile then need no wait at all.
+template <typename T, int EPI, int WMT, int WNT, int NWM, int NWN, int NS, int KS>
+__global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN * 64) / 256) void gemm_stream_kernel(GemmArgs g) {
+    constexpr int RBK = 16 * KS, ROWB = 2 * RBK, NT = NWM * NWN * 64;
+    constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32;
+    constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, SLOT_BYTES = A_BYTES + W_BYTES;
+    constexpr int A_PIECES = BM * (ROWB / 16) / NT, W_PIECES = BN * (ROWB / 16) / NT;
+    constexpr int G = A_PIECES + W_PIECES, PIECE_STRIDE = NT * 16;
+    static_assert(NS >= 4 && KS == 2, "stream kernel: 64-byte rows, ring of >= 4 slots");
+    typedef typename Elem<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    // ---- tile walk: virtual workgroup id v keeps v % 8 == bid % 8 (same XCD), then the XCD-contiguous GROUP_M raster
+    const int ntm = g.M / BM, ntn = g.N_pad / BN, ntiles = ntm * ntn;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int my_tiles = (ntiles - bid + nblk - 1) / nblk;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7;
+    const int lid_base = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8);
+    auto tile_origin = [&](int round, int &m0, int &n0) {
+        const int v = bid + round * nblk;
+        const int lid = lid_base + (v >> 3);
+        const int per_group = GROUP_M * ntn;
+        const int grp = lid / per_group, within = lid - grp * per_group;
+        const int gm = min(GROUP_M, ntm - grp * GROUP_M);
+        const int tn = within / gm;
+        m0 = (grp * GROUP_M + (within - tn * gm)) * BM; n0 = tn * BN;
+    };
+
+    const T *A = (const T *)g.A, *W = (const T *)g.W;
+    int aoff[A_PIECES], woff[W_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) { int row, sl; swz64_inv(i * NT + tid, row, sl); aoff[i] = row * g.lda + sl * 8; }
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) { int row, sl; swz64_inv(i * NT + tid, row, sl); woff[i] = row * g.ldw + sl * 8; }
+
+    const int nslots = g.K / RBK;
+    const int S = my_tiles * nslots;                // slots this workgroup streams through its ring
+    // issue side runs NS-1 slots ahead of the consume side, across tile boundaries
+    int is_round = 0, is_slot = 0, is_pos = 0, issued = 0, is_a = 0, is_w = 0;
+    if (my_tiles > 0) { int m0, n0; tile_origin(0, m0, n0); is_a = m0 * g.lda; is_w = n0 * g.ldw; }
+    auto issue_next = [&]() {
+        char *base = smem + is_pos * SLOT_BYTES + wave * 1024;
+        const T *Ab = A + is_a + is_slot * RBK, *Wb = W + is_w + is_slot * RBK;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) __builtin_amdgcn_global_load_lds(GPTR(Ab + aoff[i]), LPTR(base + i * PIECE_STRIDE), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_PIECES; ++i) __builtin_amdgcn_global_load_lds(GPTR(Wb + woff[i]), LPTR(base + A_BYTES + i * PIECE_STRIDE), 16, 0, 0);
+        ++issued;
+        is_pos = (is_pos + 1 == NS) ? 0 : is_pos + 1;
+        if (++is_slot == nslots) {
+            is_slot = 0; ++is_round;
+            if (is_round < my_tiles) { int m0, n0; tile_origin(is_round, m0, n0); is_a = m0 * g.lda; is_w = n0 * g.ldw; }
+        }
+    };
+
+    int a_rd[WMT][KS], w_rd[WNT][KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) a_rd[i][ks] = swz64_byte(wm * (WMT * 32) + i * 32 + l31, ks * 2 + hh);
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) w_rd[j][ks] = A_BYTES + swz64_byte(wn * (WNT * 32) + j * 32 + l31, ks * 2 + hh);
+    }
+    v8 fa[2][WMT], fw[2][WNT];
+    auto load_frags = [&](int buf, int pos, int ks) {
+        const char *sb = smem + pos * SLOT_BYTES;
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) fw[buf][j] = *(const v8 *)(sb + w_rd[j][ks]);
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) fa[buf][i] = *(const v8 *)(sb + a_rd[i][ks]);
+    };
+    f32x16 acc[WMT][WNT];
+    auto mma = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) acc[i][j] = Elem<T>::mfma(fa[buf][i], fw[buf][j], acc[i][j]);
+    };
+    if (S == 0) return;
+
+    // ---- prologue (once per workgroup): NS-1 slots in flight, slots 0 and 1 landed, first fragments in registers
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) if (issued < S) issue_next();
+    if (S >= NS - 1) wait_vmcnt<(NS - 3) * G>(); else wait_vmcnt<0>();
+    wg_barrier();
+    load_frags(0, 0, 0);
+
+    int pos = 0, gi = 0;                            // ring position / global index of the slot being consumed
+    for (int round = 0; round < my_tiles; ++round) {
+        // the tile's bias is fetched now and is known complete at the drain wait below (a compiler-visible s_waitcnt:
+        // no load may stay pending into the next round, or hipcc guards the loop's register reuse with vmcnt(0))
+        int m0, n0; tile_origin(round, m0, n0);
+        float bv[WNT];
+        load_bias<WNT>(g, n0 + wn * (WNT * 32) + l31, bv);
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int i = 0; i < nslots; ++i, ++gi) {
+            const int pos_next = (pos + 1 == NS) ? 0 : pos + 1;
+            if (issued < S) issue_next();           // slot gi+NS-1 into the position freed by the barrier that ended slot gi-1
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) load_frags((ks + 1) & 1, pos, ks + 1);
+                else load_frags((ks + 1) & 1, pos_next, 0);      // slot gi+1 (possibly the next tile's first) landed one iteration ago
+                mma(ks & 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+                for (int q = 0; q < WMT + WNT; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, WMT * WNT - 1 - (WMT + WNT), 0);
+            }
+            // slot gi+2 must have landed before the next iteration prefetches its fragments
+            const bool tile_end = (i == nslots - 1);
+            if (tile_end) __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) drain: nothing in flight during the epilogue's stores
+            else if (round > 0 && i < NS - 3) { /* slots gi+2 <= first NS-1 of this tile: drained before the previous epilogue */ }
+            else {
+                const int keep = min(gi + NS - 1, S - 1) - (gi + 2);         // slots allowed to stay in flight
+                if (keep >= NS - 3) wait_vmcnt<(NS - 3) * G>();
+                else if (NS > 4 && keep == 1) wait_vmcnt<G>();
+                else wait_vmcnt<0>();
+            }
+            wg_barrier();
+            pos = pos_next;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) again, unconditionally and visible to hipcc (free: the last slot's wait drained everything)
+        const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
+        if (full) epilogue<T, EPI, WMT, WNT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
+        else epilogue<T, EPI, WMT, WNT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
+    }
 }
 
 // ---- configurations: cfg = WMT*100 + NWN*10 + NS
@@ -246,6 +413,8 @@ static bool parse_cfg(int cfg, RingCfg &c) {
     c.wmt = cfg / 100; c.nwn = (cfg / 10) % 10; c.ns = cfg % 10;
     c.wnt = 2; c.nwm = 2;
     if (c.ks == 2 && (cfg == 165 || cfg == 164)) { c.wmt = 2; c.nwm = 4; c.nwn = 4; return true; }
+    if (c.ks == 2 && cfg == 945) { c.wmt = 4; c.nwn = 4; c.ns = 5; return true; }   // persistent stream kernel, 445 geometry
+    if (c.ks == 2 && cfg == 423) { c.nwn = 2; return true; }     // 4 waves, tile 256x128, 3 slots (72 KiB): two workgroups per CU
     return c.ks == 2 && (cfg == 445 || cfg == 245);
 }
 
@@ -260,11 +429,32 @@ static hipError_t launch_ring_inst(const GemmArgs &a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <typename T, int EPI>
+static hipError_t launch_stream_inst(const GemmArgs &a, hipStream_t stream) {
+    constexpr int WMT = 4, WNT = 2, NWM = 2, NWN = 4, NS = 5, KS = 2;
+    constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32, lds = NS * (BM + BN) * 32 * KS;
+    static bool attr_set = false;
+    static int n_cu = 0;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)gemm_stream_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n_cu <= 0) n_cu = 256;
+        n_cu &= ~7;                                  // the tile walk keeps a workgroup on one XCD: grid must be a multiple of 8
+        attr_set = true;
+    }
+    const int ntiles = (a.M / BM) * (a.N_pad / BN);
+    const int grid = ntiles < n_cu ? ntiles : n_cu;
+    hipLaunchKernelGGL((gemm_stream_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS>), dim3(grid), dim3(NWM * NWN * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
 template <typename T, int EPI, bool DBG>
 static hipError_t launch_ring_e(const GemmArgs &a, int cfg, hipStream_t stream) {
     switch (cfg) {
+    case 945: if constexpr (!DBG) return launch_stream_inst<T, EPI>(a, stream); else return hipErrorInvalidValue;
     case 445: return launch_ring_inst<T, EPI, 4, 2, 2, 4, 5, 2, DBG>(a, stream);
     case 245: return launch_ring_inst<T, EPI, 2, 2, 2, 4, 5, 2, DBG>(a, stream);
+    case 423: return launch_ring_inst<T, EPI, 4, 2, 2, 2, 3, 2, DBG>(a, stream);
     case 165: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 5, 2, DBG>(a, stream);      // 16 waves (4 per SIMD), 64x64 per wave, tile 256x256
     case 164: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 4, 2, DBG>(a, stream);
     default: return hipErrorInvalidValue;
@@ -286,6 +476,7 @@ static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, hipStream_t
 bool gemm_ring_supports(const GemmArgs &a, int cfg) {
     RingCfg c;
     if (!parse_cfg(cfg, c)) return false;
+    if (cfg == 945 && a.K < 16 * c.ks * c.ns) return false;
     return a.M % (c.nwm * c.wmt * 32) == 0 && a.N_pad % (c.nwn * c.wnt * 32) == 0 && a.K % (16 * c.ks) == 0 && a.K >= 32 * c.ks;
 }
 

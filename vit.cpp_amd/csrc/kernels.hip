@@ -161,8 +161,6 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream) 
 
 bool gemm_ring_supports(const GemmArgs &a, int cfg);
 hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream);
-bool gemm_pers_supports(const GemmArgs &a);
-hipError_t launch_gemm_pers(int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream);
 
 // Kernel selection.  VITX_GEMM_CFG overrides it for experiments: "v1" (128x128 two-stage kernel) or
 // WMT*100+NWN*10+NS of the ring kernel ("445": 256x256 tile 8 waves 5-slot ring; "423": 256x128 tile, 4 waves, 3 slots, 2 WG/CU).
@@ -175,6 +173,13 @@ static int gemm_cfg_override() {
     return cfg;
 }
 
+// 256x256-tile kernel flavour: the persistent stream kernel (945) unless VITX_GEMM_STREAM=0 asks for one workgroup per tile (445)
+static int wide_cfg(const GemmArgs &a) {
+    static int stream_on = -1;
+    if (stream_on < 0) { const char *e = getenv("VITX_GEMM_STREAM"); stream_on = e ? atoi(e) : 1; }
+    return (stream_on && gemm_ring_supports(a, 945)) ? 945 : 445;
+}
+
 hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
     int cfg = gemm_cfg_override();
@@ -184,10 +189,7 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream
         const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
         cfg = (a.M % 256 == 0 && t256 >= 128) ? 445 : 245;
     }
-    if (cfg >= 900) {
-        if (gemm_pers_supports(a)) return launch_gemm_pers(dtype, epi, a, cfg, stream);
-        cfg = 245;
-    }
+    if (cfg == 945 && !gemm_ring_supports(a, 945)) cfg = gemm_ring_supports(a, 445) ? 445 : 245;
     // Tail split: one 256x256 tile per CU per round means e.g. 591 tiles (N = 768) cost 3 rounds for 2.31 rounds of
     // work.  Rows that fill whole rounds keep 256x256 tiles; the remaining rows are re-tiled 128x256 (half-cost tiles)
     // in a second launch, which turns a 0.3-round remainder into ~0.35 rounds instead of a full one.
@@ -206,13 +208,14 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream
                 tail.A = (const char *)a.A + (size_t)rows_main * a.lda * 2;
                 tail.out = (char *)a.out + (size_t)rows_main * a.ldo * esz_out;
                 tail.M = a.M - rows_main; tail.M_real = a.M_real - rows_main;
-                hipError_t e = launch_gemm_ring(dtype, epi, head, 445, stream);
+                hipError_t e = launch_gemm_ring(dtype, epi, head, wide_cfg(head), stream);
                 if (e != hipSuccess) return e;
                 if (tail.M_real <= 0) return hipSuccess;
                 return launch_gemm_ring(dtype, epi, tail, 245, stream);
             }
         }
     }
+    if (cfg == 445 && gemm_cfg_override() < 0) cfg = wide_cfg(a);
     if (cfg > 0 && gemm_ring_supports(a, cfg)) return launch_gemm_ring(dtype, epi, a, cfg, stream);
     if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
     return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream) : launch_gemm_t<__bf16>(epi, a, stream);
