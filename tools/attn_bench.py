@@ -4,7 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import _pkg; _pkg.load()
 from vitcpp_amd import binding as B
-n_img, N, H = 256, 197, 12; D = H * 64
+n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 197
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+D = H * 64
 dt = torch.float16
 qkv = (torch.randn((n_img * N, 3 * D), device="cuda") * 0.8).to(dt)
 out = torch.zeros((n_img * N, D), device="cuda", dtype=dt)

@@ -25,6 +25,20 @@ template <> struct Elem<__bf16> {
 };
 template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)(T)x; }   // round-trip through the operand type
 
+// Packed pair helpers for the softmax inner loop (gfx950: v_cvt_pk_{f16,bf16}_f32, v_fma_mix_f32, v_dot2c_f32_{f16,bf16}).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Pair;
+template <> struct Pair<_Float16> {
+    typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float sum2(v2 p, float acc) { return __builtin_amdgcn_fdot2(p, v2{(_Float16)1.0f, (_Float16)1.0f}, acc, false); }
+};
+template <> struct Pair<__bf16> {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ float sum2(v2 p, float acc) { return __builtin_amdgcn_fdot2_f32_bf16(p, v2{(__bf16)1.0f, (__bf16)1.0f}, acc, false); }
+};
+// (T)a, (T)b rounded to nearest even in one instruction
+template <typename T> __device__ __forceinline__ typename Pair<T>::v2 round_pair(float a, float b) { return __builtin_convertvector((f32x2{a, b}), typename Pair<T>::v2); }
+
 // tanh-GELU of the reference (ggml_gelu_f32): 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x))),
 // evaluated as x*sigmoid(2u) = x / (1 + exp(-2u)), algebraically identical and stable in both tails.
 __device__ __forceinline__ float gelu_tanh(float x) {

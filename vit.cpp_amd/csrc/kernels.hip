@@ -348,7 +348,7 @@ hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w,
 // exp follows ggml_soft_max: e = round(exp(round(s - max))) in the operand type (fp16 LUT in ggml).
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NKT, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, (NKT <= 7 && NWAVES <= 4) ? 2 : 1) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H) {
+__global__ __launch_bounds__(NWAVES * 64, (NKT <= 9 && NWAVES <= 4) ? 2 : 1) void attention_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = NWAVES * 64;
     constexpr int NK = NKT * 32;          // padded key count
@@ -360,6 +360,16 @@ __global__ __launch_bounds__(NWAVES * 64, (NKT <= 7 && NWAVES <= 4) ? 2 : 1) voi
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const T *base = qkv + (size_t)b * N * 3 * D + h * 64;
     typedef typename Elem<T>::v8 v8;
+
+    // ---- this wave's first query fragments: issued first so their latency hides under the K/V staging
+    auto load_q = [&](int qt, v8 (&qf)[4]) {
+        const int qrow = min(qt * 32 + l31, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qrow * 3 * D + ks * 16 + hh * 8);
+    };
+    constexpr bool QPREF = NKT <= 9;      // longer sequences have no registers to spare for a prefetched Q tile
+    v8 qf[4];
+    if (QPREF && wave < NKT) load_q(wave, qf);
 
     // ---- stage K: 16-B pieces in row order (coalesced 128-B rows), all loads issued before the LDS writes
     {
@@ -407,12 +417,11 @@ __global__ __launch_bounds__(NWAVES * 64, (NKT <= 7 && NWAVES <= 4) ? 2 : 1) voi
 
 #pragma unroll 1
     for (int qt = wave; qt < NKT; qt += NWAVES) {
-        int qrow = qt * 32 + l31;
+        int lds_off = 0;
+        asm volatile("" : "+v"(lds_off));   // opaque zero: keeps the (query-independent) K / V^T fragment reads inside the loop instead of hoisted into ~220 live registers
+        const int qrow = qt * 32 + l31;
         const bool qvalid = qrow < N;
-        if (!qvalid) qrow = N - 1;
-        v8 qf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qrow * 3 * D + ks * 16 + hh * 8);
+        if (!QPREF) load_q(qt, qf);
 
         // S^T tiles: rows = keys, cols = queries
         f32x16 s[NKT];
@@ -422,35 +431,39 @@ __global__ __launch_bounds__(NWAVES * 64, (NKT <= 7 && NWAVES <= 4) ? 2 : 1) voi
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const v8 kf = *(const v8 *)(Ks + swz_byte(kt * 32 + l31, ks * 2 + hh));
+                const v8 kf = *(const v8 *)(Ks + lds_off + swz_byte(kt * 32 + l31, ks * 2 + hh));
                 s[kt] = Elem<T>::mfma(kf, qf[ks], s[kt]);
             }
         }
-        // scale (exact, 2^-3), mask padded keys, max
-        float mx = -INFINITY;
+        if (QPREF && qt + NWAVES < NKT) load_q(qt + NWAVES, qf);       // next query tile of this wave: in flight during softmax + PV
+        // mask padded keys, max of the raw scores; the 2^-3 scale is exact, so fma(s, 1/8, -max/8) == s/8 - max/8
+        float mxs = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = s[kt][r] * 0.125f;
                 if (kt == NKT - 1) {       // only the last key tile can hold padded keys
                     const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= N) v = -INFINITY;
+                    if (key >= N) s[kt][r] = -INFINITY;
                 }
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
+                mxs = fmaxf(mxs, s[kt][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+        const float nmx = -0.125f * mxs;
+        // e = round(exp(round(s/8 - max))) per ggml_soft_max, two keys per packed convert; exp(-inf) = 0 for padded keys.
+        // The row sum adds the ROUNDED values (as ggml does) with one v_dot2c per pair.
         float sum = 0.0f;
         v8 p[NKT][2];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float e = rnd<T>(__expf(rnd<T>(s[kt][r] - mx)));
-                if (kt == NKT - 1 && s[kt][r] == -INFINITY) e = 0.0f;
-                sum += e;
-                p[kt][r >> 3][r & 7] = (T)e;
+            for (int r = 0; r < 16; r += 2) {
+                const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[kt][r], 0.125f, nmx), __builtin_fmaf(s[kt][r + 1], 0.125f, nmx));
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[0], 1.44269504f, 0.0f));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[1], 1.44269504f, 0.0f));
+                const typename Pair<T>::v2 eh = round_pair<T>(e0, e1);
+                sum = Pair<T>::sum2(eh, sum);
+                p[kt][r >> 3][r & 7] = eh[0]; p[kt][r >> 3][(r & 7) + 1] = eh[1];
             }
         sum += __shfl_xor(sum, 32);
         const float inv = 1.0f / sum;
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NKT <= 7 && NWAVES <= 4) ? 2 : 1) voi
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    const v8 vf = *(const v8 *)(VT + (dt * 32 + l31) * VLD + kt * 32 + half * 16 + hh * 8);
+                    const v8 vf = *(const v8 *)((const char *)(VT + (dt * 32 + l31) * VLD + kt * 32 + half * 16 + hh * 8) + lds_off);
                     o[dt] = Elem<T>::mfma(vf, p[kt][half], o[dt]);
                 }
         }
@@ -503,9 +516,11 @@ static hipError_t launch_attention_t(const void *qkv, void *out, int n_img, int 
     case 5: return launch_attention_inst<T, 5, 4>(qkv, out, n_img, N, D, H, stream);
     case 6: return launch_attention_inst<T, 6, 4>(qkv, out, n_img, N, D, H, stream);
     case 7: {                                                                             // 197 tokens (224/16)
+        // 4 waves x 2 query tiles, two workgroups per CU (one stages K/V while the other computes): 109 us vs 124 us for
+        // one 7-wave workgroup per CU on 256 x 12 heads (VITX_ATTN_WAVES=7 keeps the latter for A/B runs)
         static int w = -1;
-        if (w < 0) { const char *e = getenv("VITX_ATTN_WAVES"); w = e ? atoi(e) : 7; }
-        return w == 4 ? launch_attention_inst<T, 7, 4>(qkv, out, n_img, N, D, H, stream) : launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream);
+        if (w < 0) { const char *e = getenv("VITX_ATTN_WAVES"); w = e ? atoi(e) : 4; }
+        return w == 7 ? launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream) : launch_attention_inst<T, 7, 4>(qkv, out, n_img, N, D, H, stream);
     }
     case 9: return launch_attention_inst<T, 9, 4>(qkv, out, n_img, N, D, H, stream);      // 257 tokens (224/14)
     case 19: return launch_attention_inst<T, 19, 4>(qkv, out, n_img, N, D, H, stream);    // 577 tokens (384/16)
