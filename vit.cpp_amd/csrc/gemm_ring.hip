@@ -63,28 +63,37 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][W
     bool col_ok[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; ++j) col_ok[j] = FULL || (col0 + j * 32) < g.N;
+    if constexpr (EPI == EPI_BIAS_RESID) {
+        // read-modify-write of the f32 residual stream in units of 16 loads (one 32x32 accumulator tile): the loads of unit
+        // u+1 are issued BEFORE the adds/stores of unit u, so only the first unit's load latency is exposed.  (Two 32-load
+        // batches in flight need 32 more registers than the K loop leaves: 60 spills, fc2 340 -> 474 us.)
+        float res[2][16];
+        auto load_unit = [&](int u, float (&dst)[16]) {          // unit u = (32-row block u/WNT, column tile u%WNT): 16 rows x this lane's column
+            const int i = u / WNT, j = u % WNT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                const bool ok = FULL || (col_ok[j] && row < g.M_real);
+                dst[r] = ok ? ((const float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] : 0.0f;
+            }
+        };
+        load_unit(0, res[0]);
+#pragma unroll
+        for (int u = 0; u < WNT * WMT; ++u) {
+            if (u + 1 < WNT * WMT) load_unit(u + 1, res[(u + 1) & 1]);
+            const int i = u / WNT, j = u % WNT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (!FULL && !(col_ok[j] && row < g.M_real)) continue;
+                ((float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] = (acc[i][j][r] + bv[j]) + res[u & 1][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
         if constexpr (EPI == EPI_BIAS_RESID) {
-            // read-modify-write of the f32 residual stream: all 32 loads of this 32-row block first
-            float res[2][16];
-            static_assert(EPI != EPI_BIAS_RESID || WNT == 2, "RMW epilogue batches two column tiles");
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const bool ok = FULL || (col_ok[j] && row < g.M_real);
-                    res[j][r] = ok ? ((const float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] : 0.0f;
-                }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (!FULL && !(col_ok[j] && row < g.M_real)) continue;
-                    ((float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] = (acc[i][j][r] + bv[j]) + res[j][r];
-                }
         } else {
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
@@ -414,7 +423,8 @@ static bool parse_cfg(int cfg, RingCfg &c) {
     c.wnt = 2; c.nwm = 2;
     if (c.ks == 2 && (cfg == 165 || cfg == 164)) { c.wmt = 2; c.nwm = 4; c.nwn = 4; return true; }
     if (c.ks == 2 && cfg == 945) { c.wmt = 4; c.nwn = 4; c.ns = 5; return true; }   // persistent stream kernel, 445 geometry
-    if (c.ks == 2 && cfg == 423) { c.nwn = 2; return true; }     // 4 waves, tile 256x128, 3 slots (72 KiB): two workgroups per CU
+    if (c.ks == 2 && cfg == 423) { c.nwn = 2; return true; }
+    if (c.ks == 2 && cfg == 825) { c.wmt = 4; c.wnt = 4; c.nwn = 2; c.ns = 5; return true; }   // 4 waves, 128x128 per wave (accumulators in AGPRs), tile 256x256     // 4 waves, tile 256x128, 3 slots (72 KiB): two workgroups per CU
     return c.ks == 2 && (cfg == 445 || cfg == 245);
 }
 
@@ -454,7 +464,6 @@ static hipError_t launch_ring_e(const GemmArgs &a, int cfg, hipStream_t stream) 
     case 945: if constexpr (!DBG) return launch_stream_inst<T, EPI>(a, stream); else return hipErrorInvalidValue;
     case 445: return launch_ring_inst<T, EPI, 4, 2, 2, 4, 5, 2, DBG>(a, stream);
     case 245: return launch_ring_inst<T, EPI, 2, 2, 2, 4, 5, 2, DBG>(a, stream);
-    case 423: return launch_ring_inst<T, EPI, 4, 2, 2, 2, 3, 2, DBG>(a, stream);
     case 165: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 5, 2, DBG>(a, stream);      // 16 waves (4 per SIMD), 64x64 per wave, tile 256x256
     case 164: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 4, 2, DBG>(a, stream);
     default: return hipErrorInvalidValue;
