@@ -3,17 +3,19 @@
 //   C[M][N] = A[M][K] . W[N][K]^T   (+ fused epilogue), A/W fp16 or bf16, f32 accumulate.
 //
 // Design (MI355X-first, see DESIGN.md "GEMM"):
-//   * waves are laid out 2(M) x NWN(N); each wave owns (WMT*32) x 64 of C as WMT x 2 MFMA 32x32x16
-//     accumulators.  Two geometries are instantiated:
-//       - "wide":  8 waves, tile 256x256, one workgroup per CU (ring of 4-5 slots, 128-160 KiB LDS);
-//       - "pair":  4 waves, tile 256x128, TWO workgroups per CU (ring of 3 slots, 72 KiB LDS each), so
-//         that one workgroup's barrier / prologue / epilogue is covered by the other's MFMAs.
+//   * waves are laid out 2(M) x 4(N); each wave owns (WMT*32) x 64 of C as WMT x 2 MFMA 32x32x16
+//     accumulators: 8 waves, tile 256x256 (WMT=4, cfg 445/945) or 128x256 (WMT=2, cfg 245: short M and
+//     the remainder rows of a launch), one workgroup per CU, ring of 5 slots (160 / 120 KiB LDS).
+//   * cfg 945 (default for the wide tile) is PERSISTENT: one workgroup per CU walks its tiles and keeps
+//     the ring running across tile boundaries (gemm_stream_kernel below).
 //   * K is consumed in slots of 32: an LDS ring of NS slots, each [A: BM x 32 | W: BN x 32] halves.
 //     Slots are filled by LDS-DMA (global_load_lds dwordx4) issued NS-1 slots ahead and retired with
 //     COUNTED s_waitcnt vmcnt(N) + one raw s_barrier per slot, so loads stay in flight across
 //     barriers (the compiler's __syncthreads() would drain them).
 //   * fragment registers are double buffered across 16-deep k-steps: the ds_read_b128 of step j+1
-//     (possibly in the next, already-landed slot) are issued under the MFMAs of step j.
+//     (possibly in the next, already-landed slot) are issued under the MFMAs of step j -- MFMA FIRST, then
+//     one read per MFMA (sched_group_barrier), so the lgkmcnt(0) in front of a k-step waits on reads that
+//     are 2+ MFMAs old instead of on the reads just issued (+5-7 %).
 //   * 64-byte LDS rows, 4 rows per 256-B bank line, 16-B slots XOR-ed with (line & 15): every
 //     ds_read_b128 lane group hits 16 distinct slots (conflict-free); the LDS image itself is
 //     lane-linear (DMA requirement), the permutation is applied to the per-lane global source address.
@@ -423,8 +425,6 @@ static bool parse_cfg(int cfg, RingCfg &c) {
     c.wnt = 2; c.nwm = 2;
     if (c.ks == 2 && (cfg == 165 || cfg == 164)) { c.wmt = 2; c.nwm = 4; c.nwn = 4; return true; }
     if (c.ks == 2 && cfg == 945) { c.wmt = 4; c.nwn = 4; c.ns = 5; return true; }   // persistent stream kernel, 445 geometry
-    if (c.ks == 2 && cfg == 423) { c.nwn = 2; return true; }
-    if (c.ks == 2 && cfg == 825) { c.wmt = 4; c.wnt = 4; c.nwn = 2; c.ns = 5; return true; }   // 4 waves, 128x128 per wave (accumulators in AGPRs), tile 256x256     // 4 waves, tile 256x128, 3 slots (72 KiB): two workgroups per CU
     return c.ks == 2 && (cfg == 445 || cfg == 245);
 }
 

@@ -163,7 +163,7 @@ bool gemm_ring_supports(const GemmArgs &a, int cfg);
 hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream);
 
 // Kernel selection.  VITX_GEMM_CFG overrides it for experiments: "v1" (128x128 two-stage kernel) or
-// WMT*100+NWN*10+NS of the ring kernel ("445": 256x256 tile 8 waves 5-slot ring; "423": 256x128 tile, 4 waves, 3 slots, 2 WG/CU).
+// WMT*100+NWN*10+NS of the ring kernel ("445": 256x256 tile, 8 waves, 5-slot ring, one workgroup per tile; "945": the same as a persistent stream kernel; "245": 128x256).
 static int gemm_cfg_override() {
     static int cfg = -2;
     if (cfg == -2) {
