@@ -77,6 +77,12 @@ int vitx_model_tensor_info(const vitx_model *m, int index, const char **name, in
 /* Decodes tensor `index` to f32 into out (n_elements floats).  Host only. */
 int vitx_model_tensor_f32(const vitx_model *m, int index, float *out, size_t n_elements);
 
+/* Re-encodes an f16/f32 model file with its 2-D "*weight" tensors in block format `ftype`
+ * (2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0), byte-identical to what the reference's offline
+ * `quantize` tool writes (quantize.cpp:34-353: header ftype, label order, which tensors, block
+ * encoders).  Host only.  VITX_ERR_ARG for another ftype, VITX_ERR_FORMAT if already quantised. */
+int vitx_quantize_file(const char *path_in, const char *path_out, int ftype);
+
 /* ---- preprocess (replaces vit_image_preprocess, vit.cpp:289-305) ------------ */
 /* u8 HWC RGB [ny][nx][3] -> f32 HWC [img_size][img_size][3], resized without
  * crop/antialias, rounded to u8, ImageNet mean/std normalised (vit.cpp:130-287). */

@@ -89,6 +89,48 @@ def test_q4_0_block_encoding_known_answer(pkg):
     assert len(raw8) == 34 and np.abs(pkg.ggml_file.dequantize(8, raw8, 32) - np.arange(-16, 16)).max() <= 16 / 127 / 2 + 1e-3
 
 
+@pytest.mark.parametrize("ftype", [2, 3, 6, 7, 8])
+def test_native_quantize_tool_is_byte_identical_to_the_python_restatement(pkg, binding, tmp_path, ftype):
+    """vitx_quantize_file (C++, quantize.cpp:34-353 rules) on an f16 file == the file the numpy block encoders write
+    from the same weights: two independent restatements of ggml's quantize_row_*_reference agree byte for byte, for
+    every block type, on real weight statistics plus adversarial rows (all-zero block, ties, +-max, denormal scale)."""
+    name = "vit_micro_patch16_64"
+    hp = pkg.synth.hparams_for(name)
+    w = pkg.synth.make_weights(hp, seed=77, head_scale=8.0)
+    fc1 = w["blocks.0.mlp.fc1.weight"]
+    fc1[0, :32] = 0.0                                        # d == 0 -> id = 0
+    fc1[1, :32] = np.tile(np.float32([0.5, -0.5]), 16)       # |x| ties: the FIRST largest wins
+    fc1[2, :32] = np.linspace(-1, 1, 32, dtype=np.float32)   # max at the end, min at the start
+    fc1[3, :32] = np.float32(1e-7)                           # scale underflows to an fp16 denormal / zero
+    fc1[4, :32] = np.float32([65504.0] + [-65504.0] * 31)    # fp16 extremes
+    src, ref, out = str(tmp_path / "f16.gguf"), str(tmp_path / "ref.gguf"), str(tmp_path / "out.gguf")
+    pkg.ggml_file.write_model(src, hp, w, ftype=1)
+    pkg.ggml_file.write_model(ref, hp, w, ftype=ftype)
+    binding.quantize_file(src, out, ftype)
+    a, b = open(ref, "rb").read(), open(out, "rb").read()
+    assert len(a) == len(b)
+    assert a == b
+    # and the result loads and dequantises through the product loader
+    m = binding.Model(out)
+    assert m.hparams.ftype == ftype
+    names = {t[0]: t[1] for t in m.tensors()}
+    assert names["blocks.0.mlp.fc1.weight"] == ftype and names["head.weight"] == ftype
+    assert names["patch_embed.proj.weight"] == 1 and names["pos_embed"] == 0 and names["norm.weight"] == 0
+
+
+def test_native_quantize_tool_errors(pkg, binding, tmp_path):
+    name = "vit_micro_patch16_64"
+    src = str(tmp_path / "f16.gguf"); pkg.synth.write_synthetic(src, name, ftype=1)
+    q = str(tmp_path / "q.gguf")
+    with pytest.raises(binding.VitxError):
+        binding.quantize_file(src, q, 1)                     # f16 is not a quantisation target (quantize.cpp:296-300)
+    with pytest.raises(binding.VitxError):
+        binding.quantize_file(str(tmp_path / "missing.gguf"), q, 2)
+    binding.quantize_file(src, q, 2)
+    with pytest.raises(binding.VitxError):
+        binding.quantize_file(q, str(tmp_path / "qq.gguf"), 8)   # already quantised input
+
+
 def _write_raw(path, hp7, labels, tensors):
     with open(path, "wb") as f:
         f.write(struct.pack("<i", 0x67676D6C))

@@ -22,7 +22,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32 = 0, 1, 2, 3
 
 EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
-    "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_preprocess_u8",
+    "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_preprocess_u8",
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_attention", "vitx_op_softmax",
 ]
@@ -68,6 +68,7 @@ def lib():
         L.vitx_model_num_tensors.argtypes = [vp]
         L.vitx_model_tensor_info.argtypes = [vp, ip, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_size_t)]
         L.vitx_model_tensor_f32.argtypes = [vp, ip, C.POINTER(C.c_float), C.c_size_t]
+        L.vitx_quantize_file.argtypes = [C.c_char_p, C.c_char_p, ip]
         L.vitx_preprocess_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, ip, C.POINTER(C.c_float)]
         L.vitx_ctx_create.argtypes = [vp, ip, ip, ip, C.POINTER(vp)]
         L.vitx_ctx_free.argtypes = [vp]
@@ -130,6 +131,11 @@ class Model:
         n = int(np.prod(ne)); a = np.empty(n, np.float32)
         check(lib().vitx_model_tensor_f32(self._h, index, a.ctypes.data_as(C.POINTER(C.c_float)), n))
         return a.reshape(tuple(reversed(ne)))
+
+
+def quantize_file(path_in: str, path_out: str, ftype: int) -> None:
+    """Native `quantize` (quantize.cpp:34-353): f16/f32 file -> q4_0/q4_1/q5_0/q5_1/q8_0 file."""
+    check(lib().vitx_quantize_file(path_in.encode(), path_out.encode(), ftype), "vitx_quantize_file")
 
 
 def preprocess(img_u8: np.ndarray, img_size: int, interp: int = BICUBIC) -> np.ndarray:

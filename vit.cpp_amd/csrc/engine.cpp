@@ -227,7 +227,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     const size_t hcols = std::max<size_t>((size_t)4 * D, (size_t)c->Kpe_pad);
     for (int i = 0; i < ns; ++i) {
         vitx_ctx::Slice &sl = c->slices[i];
-        sl.cap = (max_batch + ns - 1) / ns;
+        sl.cap = ns > 1 ? max_batch : max_batch;     // every slice can hold the whole batch: the split point is chosen per call (split_batch)
         const size_t Mpad = (size_t)round_up(sl.cap * c->N, c->tm), Bpad = (size_t)round_up(sl.cap, c->tm);
         if ((rc = c->dmalloc((void **)&sl.X, Mpad * D * 4, true))) return rc;
         if ((rc = c->dmalloc(&sl.U, Mpad * D * 2, true))) return rc;
@@ -309,6 +309,41 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     return VITX_OK;
 }
 
+// Sub-batch sizes.  One 256x256 GEMM tile per CU per round means a sub-batch is cheapest when its tile counts land just
+// under whole rounds: for ViT-B on 256 CUs 110 images are 85 row tiles = 255 / 765 / 1020 tiles for N = 768 / 2304 / 3072
+// (1, 3 and 4 rounds) while 128 images cost 2 rounds' worth of time for 1.15 rounds of proj / fc2 work.  The first
+// sub-batch size is the minimiser of a tile-round model of the four GEMMs of a layer (same tiling rules as launch_gemm);
+// VITX_SPLIT=<images> overrides it.  More than two sub-batches are split evenly.
+static double gemm_round_cost(long rows, int N, int K, int n_cu) {
+    const long ntm = (rows + 255) / 256, ntn = (N + 255) / 256, tiles = ntm * ntn, rounds = tiles / n_cu, rem = tiles % n_cu;
+    const double slots = K / 32.0, t_tile = slots * 0.98 + 3.5, t_half = slots * 0.6 + 3.0;
+    if (rounds >= 1 && rem > 0 && rem <= n_cu * 6 / 10) {
+        const long m_main = rounds * n_cu / ntn, half_tiles = ((ntm - m_main) * 2) * ntn;
+        return rounds * t_tile + (double)((half_tiles + n_cu - 1) / n_cu) * t_half;
+    }
+    if (tiles < 128) return (double)(((rows + 127) / 128 * ntn + n_cu - 1) / n_cu) * t_half;
+    return (double)((tiles + n_cu - 1) / n_cu) * t_tile;
+}
+static void split_batch(const vitx_ctx *c, int n, int ns, int *m) {
+    const int base = n / ns, extra = n % ns;
+    for (int i = 0; i < ns; ++i) m[i] = base + (i < extra ? 1 : 0);
+    if (ns != 2) return;
+    static const int forced = getenv("VITX_SPLIT") ? atoi(getenv("VITX_SPLIT")) : 0;
+    if (forced > 0 && forced < n) { m[0] = forced; m[1] = n - forced; return; }
+    static int n_cu = 0;
+    if (!n_cu) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device); if (n_cu <= 0) n_cu = 256; }
+    const int D = c->D;
+    auto layer = [&](int imgs) {
+        const long rows = (long)imgs * c->N;
+        return gemm_round_cost(rows, 3 * D, D, n_cu) + gemm_round_cost(rows, D, D, n_cu) + gemm_round_cost(rows, 4 * D, D, n_cu) + gemm_round_cost(rows, D, 4 * D, n_cu);
+    };
+    double best = layer(m[0]) + layer(m[1]);
+    for (int s1 = std::max(8, n / 4); s1 <= n / 2; ++s1) {
+        const double cost = layer(s1) + layer(n - s1);
+        if (cost < best * 0.97) { best = cost; m[0] = s1; m[1] = n - s1; }   // move off the even split only for a clear (>3 %) modelled gain
+    }
+}
+
 int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, void *stream) {
     if (!c || !d_imgs || !d_probs) { set_error("vitx_forward_device: NULL argument"); return VITX_ERR_ARG; }
     if (n <= 0 || n > c->max_batch) { set_error("vitx_forward_device: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
@@ -317,34 +352,26 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     // while per-kernel profiling is on, sub-batches run back to back on the caller's stream so that every
     // event pair brackets one kernel running alone (exclusive durations, comparable with rocprofv3 --stats)
     static const bool serial_env = getenv("VITX_SLICES_SERIAL") != nullptr;     // for rocprofv3 runs that should match the profiled steps
-    const int ns = (c->nslices > 1 && n >= 8 * c->nslices && !c->prof_on && !serial_env) ? c->nslices : 1;
-    if (ns == 1) {
-        if (n > c->slices[0].cap) {     // a multi-slice context asked for a small-but-too-big single slice: run the slices back to back
-            int off = 0, rc;
-            for (int i = 0; i < c->nslices && off < n; ++i) {
-                const int m = std::min(c->slices[i].cap, n - off);
-                if ((rc = forward_slice(c, c->slices[i], st, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, m, (float *)d_probs + (size_t)off * c->C,
-                                        d_logits ? (float *)d_logits + (size_t)off * c->C : nullptr))) return rc;
-                off += m;
-            }
-            return VITX_OK;
-        }
-        return forward_slice(c, c->slices[0], st, d_imgs, n, d_probs, d_logits);
-    }
+    const bool serial = c->prof_on || serial_env;
+    const int ns = (c->nslices > 1 && n >= 8 * c->nslices) ? c->nslices : 1;
+    if (ns == 1) return forward_slice(c, c->slices[0], st, d_imgs, n, d_probs, d_logits);
+    int m[4];
+    split_batch(c, n, ns, m);
     // fork: every slice stream waits for the caller's stream, runs its contiguous sub-batch, and the caller's stream joins
-    HIP_TRY(hipEventRecord(c->fork, st));
-    const int base = n / ns, extra = n % ns;
+    if (!serial) HIP_TRY(hipEventRecord(c->fork, st));
     int off = 0;
     for (int i = 0; i < ns; ++i) {
         vitx_ctx::Slice &sl = c->slices[i];
-        const int m = base + (i < extra ? 1 : 0);
-        HIP_TRY(hipStreamWaitEvent(sl.stream, c->fork, 0));
-        int rc = forward_slice(c, sl, sl.stream, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, m, (float *)d_probs + (size_t)off * c->C,
+        hipStream_t ss = serial ? st : sl.stream;
+        if (!serial) HIP_TRY(hipStreamWaitEvent(sl.stream, c->fork, 0));
+        int rc = forward_slice(c, sl, ss, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, m[i], (float *)d_probs + (size_t)off * c->C,
                                d_logits ? (float *)d_logits + (size_t)off * c->C : nullptr);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(sl.done, sl.stream));
-        HIP_TRY(hipStreamWaitEvent(st, sl.done, 0));
-        off += m;
+        if (!serial) {
+            HIP_TRY(hipEventRecord(sl.done, sl.stream));
+            HIP_TRY(hipStreamWaitEvent(st, sl.done, 0));
+        }
+        off += m[i];
     }
     return VITX_OK;
 }
