@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 # HBM-side bytes per launch of the GEMM kernels from the separate rocprofv3 --pmc passes committed under profiles/
 # (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); bf16, batch 256.
-HBM_TRAFFIC_GB = {"gemm_fc1_gelu": 0.371, "gemm_qkv_bias": 0.236, "gemm_fc2_resid": 0.274, "gemm_proj_resid": 0.274}   # per 128-image launch; resid: proj/fc2 share one kernel symbol (mean)
+HBM_TRAFFIC_GB = {"gemm_fc1_gelu": 0.353, "gemm_qkv_bias": 0.278, "gemm_fc2_resid": 0.334, "gemm_proj_resid": 0.334}   # per logical launch (one sub-batch: persistent kernel + remainder-row kernel); resid: proj/fc2 share kernel symbols (mean)
 PEAK_TFLOPS = 2516.6      # dense bf16/fp16 MFMA, 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH: ~2.5 PF)
 
 
@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--ftype", default="f16", choices=["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"], help="weight file type (BASELINE config 5: q4_0)")
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the secondary u8-from-host measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,11 +63,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # weights: random-init of the named architecture in the reference's file format
+    ftype = {"f16": 1, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}[args.ftype]
     if rank == 0:
-        path = pkg.synth.cached_synthetic(args.model, head_scale=8.0)
+        path = pkg.synth.cached_synthetic(args.model, ftype=ftype, head_scale=8.0)
     if dist is not None:
         dist.barrier()
-    path = pkg.synth.cached_synthetic(args.model, head_scale=8.0)
+    path = pkg.synth.cached_synthetic(args.model, ftype=ftype, head_scale=8.0)
     hp = pkg.synth.hparams_for(args.model)
     gflop = pkg.synth.gflop_per_image(hp)
     S, C, B = hp.img_size, hp.num_classes, args.batch
@@ -116,6 +119,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # secondary, NOT the metric: the same step fed from host memory -- u8 images in pinned RAM -> H2D -> device-side
+    # vit_image_preprocess (bicubic, here 224 -> 224) -> forward; PCIe-inclusive rate for DESIGN.md
+    host_feed = None
+    if world == 1 and not args.no_host_feed:
+        u8_pinned = u8.pin_memory()
+        d_u8 = torch.empty_like(u8, device="cuda")
+        imgs2 = torch.empty_like(imgs)
+        def fed_step():
+            d_u8.copy_(u8_pinned, non_blocking=True)
+            binding.preprocess_device(d_u8.data_ptr(), B, S, S, S, imgs2.data_ptr(), binding.BICUBIC, stream)
+            ctx.forward_device(imgs2.data_ptr(), B, probs.data_ptr(), 0, stream)
+        for _ in range(2): fed_step()
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        nfed = max(3, min(10, args.steps))
+        for _ in range(nfed): fed_step()
+        torch.cuda.synchronize()
+        host_feed = B * nfed / (time.perf_counter() - tf0)
+        # restore the probabilities of the resident batch for the sanity check below
+        ctx.forward_device(imgs.data_ptr(), B, probs.data_ptr(), 0, stream); torch.cuda.synchronize()
+
     sanity = probs.sum(1)
     assert torch.isfinite(probs).all() and float((sanity - 1).abs().max()) < 1e-3, "forward produced invalid probabilities"
 
@@ -127,9 +151,9 @@ def main():
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.dtype}, batch={B} per GPU, {S}x{S}x3 f32 HWC inputs in HBM, random-init weights in the reference's file format",
+            "config": {"workload": f"{args.model} {args.dtype} ({args.ftype} weight file), batch={B} per GPU, {S}x{S}x3 f32 HWC inputs in HBM, random-init weights in the reference's file format",
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, replicated weights, 1 all-gather of probs/step)" if world > 1 else "single GPU"},
-            "gflop_per_image": round(gflop, 4),
+            "gflop_per_image": round(gflop, 4), "weights": args.ftype,
             "mfma_roofline_frac_whole_forward": round(value / world * gflop / 1e3 / PEAK_TFLOPS, 4),
         }
         # roofline of the dominant kernel: algorithmic flops / HIP-event time on the launch stream
@@ -141,7 +165,7 @@ def main():
             dom = max(gemms, key=lambda p: p["busy_ms"])
             tf = dom["flops"] / (dom["busy_ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_GB.get(dom["name"]), "traffic_unit": "GB per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_forward_rocprofv3_stats.txt)",
+                               "frac": round(tf / PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_GB.get(dom["name"]), "traffic_unit": "GB per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_final_rocprofv3_summary.txt)",
                                "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "flops_per_launch": dom["flops"] / dom["launches"]}
             out["roofline"]["launches_per_step"] = dom["launches"] / prof_steps
             out["roofline"]["measured_over"] = f"last {prof_steps} of the {args.steps} timed steps"
@@ -150,6 +174,8 @@ def main():
             out["kernel_breakdown"] = {p["name"]: {"busy_ms_per_step": round(p["busy_ms"] / prof_steps, 4), "share": round(p["busy_ms"] / tot, 4),
                                                     "TFLOPs": round(p["flops"] / (p["busy_ms"] * 1e-3) / 1e12, 1) if p["flops"] else None,
                                                     "GBps_algorithmic": round(p["bytes"] / (p["busy_ms"] * 1e-3) / 1e9, 1)} for p in prof}
+        if host_feed is not None:
+            out["host_fed_images_per_s"] = {"value": round(host_feed, 1), "what": "secondary, not the metric: u8 batch in pinned host RAM -> H2D (PCIe) -> device bicubic preprocess -> forward, serial on one stream"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             om = O.OracleModel(path)

@@ -88,6 +88,11 @@ int vitx_quantize_file(const char *path_in, const char *path_out, int ftype);
  * crop/antialias, rounded to u8, ImageNet mean/std normalised (vit.cpp:130-287). */
 int vitx_preprocess_u8(const uint8_t *hwc, int nx, int ny, int img_size, int interp, float *out_hwc);
 
+/* The same on the GPU for n images of one source size: d_hwc u8 [n][ny][nx][3] -> d_out f32
+ * [n][img_size][img_size][3], both device pointers; only enqueues on `stream`.  Bit-identical
+ * to vitx_preprocess_u8 (same operations in the same order, IEEE division, no FMA contraction). */
+int vitx_preprocess_u8_device(const void *d_hwc, int n, int nx, int ny, int img_size, int interp, void *d_out_hwc, void *stream);
+
 /* ---- execution context (replaces vit_state + the per-call graph build) ------ */
 /* Uploads the weights to `device` in `dtype` and allocates all activation scratch
  * for up to max_batch images once (the reference reallocates per call, vit.cpp:1009-1035).

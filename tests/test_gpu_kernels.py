@@ -145,3 +145,25 @@ def test_softmax_matches_ggml_lut(binding, oracle, torch_gpu):
     got = out.cpu().numpy()
     assert np.abs(got - ref).max() <= 2e-6
     assert np.abs(got.sum(1) - 1).max() <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (224, 224), (500, 31), (1, 1), (640, 480), (408, 612)])
+def test_device_preprocess_is_bit_identical_to_host_and_oracle(binding, oracle, torch_gpu, shape):
+    """vitx_preprocess_u8_device (HIP) == vitx_preprocess_u8 (host) == oracle restatement of vit_image_preprocess
+    (vit.cpp:130-305), bit for bit: up- and down-scaling, both interpolations, 1x1 and extreme aspect ratios, and a
+    batch of 3 same-sized images in one launch."""
+    torch = torch_gpu
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    imgs = rng.integers(0, 256, size=(3, shape[0], shape[1], 3), dtype=np.uint8)
+    d_in = _dev(torch, imgs)
+    for mode, code in (("bicubic", binding.BICUBIC), ("bilinear", binding.BILINEAR)):
+        for S in (64, 224, 384):
+            d_out = torch.empty((3, S, S, 3), dtype=torch.float32, device="cuda")
+            binding.preprocess_device(d_in.data_ptr(), 3, shape[1], shape[0], S, d_out.data_ptr(), code)
+            _sync(torch)
+            got = d_out.cpu().numpy()
+            for b in range(3):
+                assert np.array_equal(got[b], binding.preprocess(imgs[b], S, code)), (mode, S, b)
+            assert np.array_equal(got[0], oracle.preprocess(imgs[0], S, mode)), (mode, S)
+    with pytest.raises(binding.VitxError):
+        binding.preprocess_device(d_in.data_ptr(), 3, shape[1], shape[0], 224, d_in.data_ptr(), 7)

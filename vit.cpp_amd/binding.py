@@ -22,7 +22,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32 = 0, 1, 2, 3
 
 EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
-    "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_preprocess_u8",
+    "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_attention", "vitx_op_softmax",
 ]
@@ -70,6 +70,7 @@ def lib():
         L.vitx_model_tensor_f32.argtypes = [vp, ip, C.POINTER(C.c_float), C.c_size_t]
         L.vitx_quantize_file.argtypes = [C.c_char_p, C.c_char_p, ip]
         L.vitx_preprocess_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, ip, C.POINTER(C.c_float)]
+        L.vitx_preprocess_u8_device.argtypes = [vp, ip, ip, ip, ip, ip, vp, vp]
         L.vitx_ctx_create.argtypes = [vp, ip, ip, ip, C.POINTER(vp)]
         L.vitx_ctx_free.argtypes = [vp]
         L.vitx_ctx_max_batch.argtypes = [vp]
@@ -144,6 +145,11 @@ def preprocess(img_u8: np.ndarray, img_size: int, interp: int = BICUBIC) -> np.n
     out = np.empty((img_size, img_size, 3), np.float32)
     check(lib().vitx_preprocess_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), nx, ny, img_size, interp, out.ctypes.data_as(C.POINTER(C.c_float))), "vitx_preprocess_u8")
     return out
+
+
+def preprocess_device(d_u8: int, n: int, nx: int, ny: int, img_size: int, d_out: int, interp: int = BICUBIC, stream: int = 0) -> None:
+    """vit_image_preprocess on the GPU (device pointers; enqueue only)."""
+    check(lib().vitx_preprocess_u8_device(d_u8, n, nx, ny, img_size, interp, d_out, stream or None), "vitx_preprocess_u8_device")
 
 
 class Context:

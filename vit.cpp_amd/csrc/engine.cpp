@@ -471,4 +471,12 @@ int vitx_op_softmax(const void *logits, void *probs, int rows, int cols, int ld,
     return VITX_OK;
 }
 
+int vitx_preprocess_u8_device(const void *d_hwc, int n, int nx, int ny, int img_size, int interp, void *d_out, void *stream) {
+    if (!d_hwc || !d_out || n <= 0 || nx <= 0 || ny <= 0 || img_size <= 0) { set_error("vitx_preprocess_u8_device: invalid argument"); return VITX_ERR_ARG; }
+    if (interp != VITX_BICUBIC && interp != VITX_BILINEAR) { set_error("vitx_preprocess_u8_device: interpolation mode %d is not supported", interp); return VITX_ERR_ARG; }
+    hipError_t e = launch_preprocess(d_hwc, (float *)d_out, n, nx, ny, img_size, interp == VITX_BICUBIC, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_preprocess_u8_device: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
+
 }  // extern "C"

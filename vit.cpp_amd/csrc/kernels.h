@@ -43,5 +43,6 @@ hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w,
 hipError_t launch_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream);
 // class softmax with the reference's fp16 (or bf16) exp rounding (vit.cpp:931)
 hipError_t launch_softmax(int dtype, const float *logits, float *probs, int rows, int cols, int ld, hipStream_t stream);
+hipError_t launch_preprocess(const void *u8, float *out, int n, int nx, int ny, int S, int bicubic, hipStream_t stream);
 
 }  // namespace vitx

@@ -562,4 +562,72 @@ hipError_t launch_softmax(int dtype, const float *logits, float *probs, int rows
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Device-side vit_image_preprocess (vit.cpp:289-305; bicubic 204-287, bilinear 130-196): u8 HWC
+// [n][ny][nx][3] -> f32 HWC [n][S][S][3], one thread per output pixel.  Operation for operation the
+// host version in preprocess.cpp (double cubic coefficients narrowed to float, float polynomial,
+// roundf / clamp / narrow to u8, (q - mean) / std with IEEE division; the library is built with
+// -ffp-contract=off), so the two agree bit for bit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pp_norm(float v, int k) {
+    const float mean = k == 0 ? 123.675f : (k == 1 ? 116.280f : 103.530f);
+    const float sd = k == 0 ? 58.395f : (k == 1 ? 57.120f : 57.375f);
+    const unsigned char q = (unsigned char)fminf(fmaxf(roundf(v), 0.0f), 255.0f);
+    return ((float)q - mean) / sd;
+}
+__device__ __forceinline__ float pp_cubic(float p0, float p1, float p2, float p3, float t) {
+    const float d0 = p0 - p1, d2 = p2 - p1, d3 = p3 - p1;
+    const float a1 = (float)(-1.0 / 3 * d0 + d2 - 1.0 / 6 * d3);
+    const float a2 = (float)(1.0 / 2 * d0 + 1.0 / 2 * d2);
+    const float a3 = (float)(-1.0 / 6 * d0 - 1.0 / 2 * d2 + 1.0 / 6 * d3);
+    return p1 + a1 * t + a2 * t * t + a3 * t * t * t;
+}
+__device__ __forceinline__ int pp_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+template <bool BICUBIC>
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char *__restrict__ src, float *__restrict__ dst, int n, int nx, int ny, int S) {
+    const long total = (long)n * S * S;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(id / ((long)S * S)), rem = (int)(id - (long)b * S * S), i = rem / S, j = rem - i * S;
+        const unsigned char *im = src + (size_t)b * nx * ny * 3;
+        float *o = dst + (size_t)id * 3;
+        if (BICUBIC) {
+            const float tx = (float)nx / (float)S, ty = (float)ny / (float)S;
+            const int y = (int)(ty * i), x = (int)(tx * j);
+            const float dy = ty * i - y, dx = tx * j - x;
+            const int x0 = pp_clamp(x - 1, 0, nx - 1), x1 = pp_clamp(x, 0, nx - 1), x2 = pp_clamp(x + 1, 0, nx - 1), x3 = pp_clamp(x + 2, 0, nx - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float C[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned char *r = im + (size_t)pp_clamp(y - 1 + jj, 0, ny - 1) * nx * 3 + k;
+                    C[jj] = pp_cubic(r[x0 * 3], r[x1 * 3], r[x2 * 3], r[x3 * 3], dx);
+                }
+                o[k] = pp_norm(pp_cubic(C[0], C[1], C[2], C[3], dy), k);
+            }
+        } else {
+            const float xs = nx / (float)S, ys = ny / (float)S;
+            const float sy = (i + 0.5f) * ys - 0.5f, sx = (j + 0.5f) * xs - 0.5f;
+            const int y0 = sy < 0.0f ? 0 : (int)floorf(sy), y1 = y0 + 1 < ny - 1 ? y0 + 1 : ny - 1;
+            const int x0 = sx < 0.0f ? 0 : (int)floorf(sx), x1 = x0 + 1 < nx - 1 ? x0 + 1 : nx - 1;
+            const float dy = sy - y0, dx = sx - x0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v00 = im[3 * ((size_t)y0 * nx + x0) + c], v01 = im[3 * ((size_t)y0 * nx + x1) + c];
+                const float v10 = im[3 * ((size_t)y1 * nx + x0) + c], v11 = im[3 * ((size_t)y1 * nx + x1) + c];
+                const float v0 = v00 * (1.0f - dx) + v01 * dx, v1 = v10 * (1.0f - dx) + v11 * dx;
+                o[c] = pp_norm(v0 * (1.0f - dy) + v1 * dy, c);
+            }
+        }
+    }
+}
+hipError_t launch_preprocess(const void *u8, float *out, int n, int nx, int ny, int S, int bicubic, hipStream_t stream) {
+    const long total = (long)n * S * S;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 256L * 64);
+    if (bicubic) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const unsigned char *)u8, out, n, nx, ny, S);
+    else hipLaunchKernelGGL(preprocess_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const unsigned char *)u8, out, n, nx, ny, S);
+    return hipGetLastError();
+}
+
 }  // namespace vitx
