@@ -57,7 +57,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("VITX_FORCE_DIST"):      # VITX_FORCE_DIST: exercise the RCCL path with one rank (smoke test of the N>1 code)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -89,7 +89,7 @@ def main():
 
     def step():
         ctx.forward_device(imgs.data_ptr(), B, probs.data_ptr(), 0, stream)
-        if world > 1:
+        if dist is not None:
             state["all"] = pkg.dist.gather_probs(probs, world * B)     # the one collective: [world*B, C] class probabilities
 
     for _ in range(args.warmup):
@@ -147,7 +147,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         out = {
-            "metric": "images/sec ViT-B/16 224^2 bs=256 per GPU (forward, synthetic, HBM-resident inputs)",
+            "metric": ("images/sec ViT-B/16 224^2 bs=256 per GPU" if (args.model == "vit_base_patch16_224" and B == 256) else f"images/sec {args.model} bs={B} per GPU") + " (forward, synthetic, HBM-resident inputs)",
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -208,3 +208,19 @@ def test_quantised_file_runs_dequantised(pkg, binding, oracle, torch_gpu, tmp_pa
     _, ggml_sem = om.forward(imgs, oracle.REF)                # q8_0 activations like ggml: looser, stated tolerance
     assert np.abs(probs - ggml_sem).max() <= 2e-2
     assert (probs.argmax(1) == ggml_sem.argmax(1)).all()
+
+
+def test_bench_rccl_path_single_rank(torch_gpu):
+    """bench.py's N>1 code path (process group on RCCL, barrier, the one all-gather of probabilities per step, MAX
+    all-reduce of the elapsed time) driven with ONE rank through torch.distributed.run -- what the driver launches per GPU."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VITX_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--model", "vit_tiny_patch16_224", "--batch", "32",
+           "--no-cpu-baseline", "--no-host-feed"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "images/s" and d["scaling"] == "weak"
