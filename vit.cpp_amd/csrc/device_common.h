@@ -41,9 +41,24 @@ template <typename T> __device__ __forceinline__ typename Pair<T>::v2 round_pair
 
 // tanh-GELU of the reference (ggml_gelu_f32): 0.5*x*(1+tanh(sqrt(2/pi)*x*(1+0.044715*x*x))),
 // evaluated as x*sigmoid(2u) = x / (1 + exp(-2u)), algebraically identical and stable in both tails.
+// With u = c*x*(1 + a*x^2): exp(-2u) = exp2(x * (B + A*x^2)), B = -2*c*log2(e), A = B*a -- 3 multiplies, 1 fma, 1 add,
+// v_exp_f32 and v_rcp_f32 per element (the straightforward form needs 7 multiplies; the GELU epilogue is VALU-bound).
+// Saturates correctly: x -> -inf gives exp2(+inf) = inf, rcp = 0, result -0; x -> +inf gives exp2(-inf) = 0, result x.
 __device__ __forceinline__ float gelu_tanh(float x) {
-    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+    constexpr float B = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
+    constexpr float A = B * 0.044715f;
+    const float p = __builtin_fmaf(x * x, A, B);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+}
+
+// two elements at a time: the multiplies / fma / add become v_pk_*_f32 (exp and rcp stay scalar, quarter rate)
+__device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
+    constexpr float B = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
+    constexpr float A = B * 0.044715f;
+    const f32x2 p = __builtin_elementwise_fma(x * x, f32x2{A, A}, f32x2{B, B});
+    const f32x2 t = x * p;
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+    return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -100,6 +100,19 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][W
 #pragma unroll
             for (int j = 0; j < WNT; ++j) {
                 const int col = col0 + j * 32;
+                if constexpr (EPI == EPI_BIAS_GELU) {
+                    // two rows at a time: bias, round to the operand type (ggml's fp16 LUT input), packed tanh-GELU, round
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);          // r even: rows `row` and `row + 1`
+                        const typename Pair<T>::v2 xin = round_pair<T>(acc[i][j][r] + bv[j], acc[i][j][r + 1] + bv[j]);
+                        const f32x2 y = gelu_tanh2(f32x2{(float)xin[0], (float)xin[1]});
+                        const typename Pair<T>::v2 yo = round_pair<T>(y[0], y[1]);
+                        if (FULL || (col_ok[j] && row < g.M_real)) ((T *)g.out)[(size_t)row * g.ldo + col] = yo[0];
+                        if (FULL || (col_ok[j] && row + 1 < g.M_real)) ((T *)g.out)[(size_t)(row + 1) * g.ldo + col] = yo[1];
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
