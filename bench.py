@@ -98,10 +98,10 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    # per-kernel HIP events (on the launch stream) bracket every launch of the LAST prof_steps timed steps only: while
+    # per-kernel HIP events (on the launch stream) bracket every launch of the LAST timed step only (prof_steps = 1): while
     # they are on, the engine runs its two sub-batches back to back on one stream (exclusive kernel durations, ~6 %
     # slower than the two-stream production schedule the other steps use)
-    prof_steps = 0 if args.no_profile else min(2, args.steps)
+    prof_steps = 0 if args.no_profile else min(1, args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof_steps and i == args.steps - prof_steps:

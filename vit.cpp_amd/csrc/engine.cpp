@@ -327,9 +327,19 @@ static double gemm_round_cost(long rows, int N, int K, int n_cu) {
 static void split_batch(const vitx_ctx *c, int n, int ns, int *m) {
     const int base = n / ns, extra = n % ns;
     for (int i = 0; i < ns; ++i) m[i] = base + (i < extra ? 1 : 0);
+    if (const char *e = getenv("VITX_SPLIT")) {          // experiments: "110" or "110,110" = sizes of the first ns-1 sub-batches
+        int left = n, i = 0;
+        for (const char *p = e; i < ns - 1 && *p; ++i) {
+            const int v = atoi(p);
+            if (v <= 0 || v >= left) break;
+            m[i] = v; left -= v;
+            while (*p && *p != ',') ++p;
+            if (*p == ',') ++p;
+        }
+        if (i == ns - 1) { m[ns - 1] = left; return; }
+        for (int k = 0; k < ns; ++k) m[k] = base + (k < extra ? 1 : 0);
+    }
     if (ns != 2) return;
-    static const int forced = getenv("VITX_SPLIT") ? atoi(getenv("VITX_SPLIT")) : 0;
-    if (forced > 0 && forced < n) { m[0] = forced; m[1] = n - forced; return; }
     static int n_cu = 0;
     if (!n_cu) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device); if (n_cu <= 0) n_cu = 256; }
     const int D = c->D;
