@@ -168,3 +168,30 @@ def test_oracle_quantised_weights(pkg, oracle, ftype, tmp_path):
     _, pq_ = oracle.OracleModel(pq).forward(imgs, oracle.REF)
     assert np.isfinite(pq_).all() and np.abs(pq_.sum(1) - 1).max() < 1e-5
     assert np.abs(pq_ - p16).max() < (0.08 if ftype in (2, 3) else 0.04)
+
+
+def test_hf_converter_round_trip(pkg, oracle, binding, tmp_path):
+    """vit.cpp_amd/convert.py: a random-init HF ViTForImageClassification converted to the legacy-ggml file must (a) pass the
+    product loader's acceptance rules and (b) reproduce the HF f32 logits through the oracle's no-rounding mode -- the
+    fused qkv order, the reversed dims and the bias reshape of the writer are all exercised (convert-pth-to-ggml.py:141-158)."""
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    torch.manual_seed(7)
+    cfg = tr.ViTConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, hidden_act="gelu_pytorch_tanh",
+                       layer_norm_eps=1e-6, image_size=64, patch_size=16, num_labels=10, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                       qkv_bias=True, id2label={i: f"class_{i}" for i in range(10)}, label2id={f"class_{i}": i for i in range(10)})
+    m = tr.ViTForImageClassification(cfg).eval()
+    with torch.no_grad():                                   # make every parameter non-trivial (HF zero-inits biases)
+        for p_ in m.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+    path = str(tmp_path / "hf.gguf")
+    hp = pkg.convert.convert_hf_model(m, path, ftype=0)      # f32 payload except the patch kernel (reference rule)
+    assert (hp.hidden_size, hp.num_hidden_layers, hp.num_classes) == (128, 2, 10)
+    pm = binding.Model(path)                                 # the product loader accepts it
+    assert pm.label(3) == "class_3" and len(pm.tensors()) == 4 + 12 * 2 + 4
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(3, 64, seed=11))
+    with torch.no_grad():
+        hf = m(pixel_values=torch.from_numpy(imgs).permute(0, 3, 1, 2).contiguous()).logits.numpy()
+    lg, _ = oracle.OracleModel(path).forward(imgs, oracle.IDEAL)
+    # the patch kernel is stored in fp16 (vit.cpp:515 requires it): that rounding is the only parameter difference
+    assert np.abs(lg - hf).max() <= 2e-3, np.abs(lg - hf).max()

@@ -5,4 +5,4 @@ C++ vit.h mirror; this Python package is plumbing for tests and bench.py: the
 file-format writer, synthetic weights, and a ctypes binding over the C ABI.
 Import it through the repo-root helper: `import _pkg; vit = _pkg.load()`.
 """
-from . import dist, ggml_file, synth  # noqa: F401
+from . import convert, dist, ggml_file, synth  # noqa: F401

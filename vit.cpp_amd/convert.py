@@ -1,0 +1,76 @@
+"""Converter: a HuggingFace `transformers` ViTForImageClassification -> the reference's legacy-ggml ".gguf" file.
+
+Counterpart of the reference's /root/reference/convert-pth-to-ggml.py (which needs `timm`): same output layout
+(writer rules convert-pth-to-ggml.py:105-158 live in ggml_file.write_model), different source naming -- HF splits
+the fused qkv projection into query/key/value (concatenated here in timm's q,k,v order, vit.cpp:826-834) and calls
+the sub-modules `vit.encoder.layer.N.*` (transformers < 5) or `vit.layers.N.*` (>= 5).  Offline tool, not on the
+compute path.  The model must use tanh-GELU or exact GELU weights trained for it: the forward path implements
+ggml_gelu (tanh form, vit.cpp:889-893) only.
+
+    python -m ... convert.py <hf_model_dir_or_name> <out.gguf> [--ftype 1]
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+from .ggml_file import HParams, write_model
+
+
+def state_dict_to_timm(sd: Dict[str, np.ndarray], num_layers: int) -> Dict[str, np.ndarray]:
+    """Rename / fuse an HF ViTForImageClassification state dict (numpy arrays) into timm's names, in the tensor
+    order the reference's loader expects to find them (vit.cpp:512-574)."""
+    new = "vit.layers.0.attention.q_proj.weight" in sd
+    out: Dict[str, np.ndarray] = {}
+    out["cls_token"] = sd["vit.embeddings.cls_token"]
+    out["pos_embed"] = sd["vit.embeddings.position_embeddings"]
+    out["patch_embed.proj.weight"] = sd["vit.embeddings.patch_embeddings.projection.weight"]
+    out["patch_embed.proj.bias"] = sd["vit.embeddings.patch_embeddings.projection.bias"]
+    for i in range(num_layers):
+        q = f"vit.layers.{i}." if new else f"vit.encoder.layer.{i}."
+        p = f"blocks.{i}."
+        qkv = ("attention.q_proj", "attention.k_proj", "attention.v_proj") if new else \
+              ("attention.attention.query", "attention.attention.key", "attention.attention.value")
+        o = "attention.o_proj" if new else "attention.output.dense"
+        f1 = "mlp.fc1" if new else "intermediate.dense"
+        f2 = "mlp.fc2" if new else "output.dense"
+        out[p + "norm1.weight"] = sd[q + "layernorm_before.weight"]; out[p + "norm1.bias"] = sd[q + "layernorm_before.bias"]
+        out[p + "attn.qkv.weight"] = np.concatenate([sd[q + n + ".weight"] for n in qkv], 0)
+        out[p + "attn.qkv.bias"] = np.concatenate([sd[q + n + ".bias"] for n in qkv], 0)
+        out[p + "attn.proj.weight"] = sd[q + o + ".weight"]; out[p + "attn.proj.bias"] = sd[q + o + ".bias"]
+        out[p + "norm2.weight"] = sd[q + "layernorm_after.weight"]; out[p + "norm2.bias"] = sd[q + "layernorm_after.bias"]
+        out[p + "mlp.fc1.weight"] = sd[q + f1 + ".weight"]; out[p + "mlp.fc1.bias"] = sd[q + f1 + ".bias"]
+        out[p + "mlp.fc2.weight"] = sd[q + f2 + ".weight"]; out[p + "mlp.fc2.bias"] = sd[q + f2 + ".bias"]
+    out["norm.weight"] = sd["vit.layernorm.weight"]; out["norm.bias"] = sd["vit.layernorm.bias"]
+    out["head.weight"] = sd["classifier.weight"]; out["head.bias"] = sd["classifier.bias"]
+    return {k: np.ascontiguousarray(np.asarray(v, np.float32)) for k, v in out.items()}
+
+
+def convert_hf_model(model, path: str, ftype: int = 1) -> HParams:
+    """model: transformers.ViTForImageClassification (eval).  Writes `path`; returns the hparams written."""
+    cfg = model.config
+    if cfg.hidden_size // cfg.num_attention_heads != 64:
+        raise ValueError("the forward path supports head_dim 64 only (every model the reference converts)")
+    hp = HParams(cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_labels, cfg.patch_size, cfg.image_size, ftype)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    tensors = state_dict_to_timm(sd, cfg.num_hidden_layers)
+    id2label = {int(k): str(v) for k, v in (getattr(cfg, "id2label", None) or {}).items()} or None
+    write_model(path, hp, tensors, id2label=id2label, ftype=ftype)
+    return hp
+
+
+def main(argv=None) -> int:
+    import argparse
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("model"); ap.add_argument("out"); ap.add_argument("--ftype", type=int, default=1, help="0 f32, 1 f16 (default), 2/3/6/7/8 q4_0/q4_1/q5_0/q5_1/q8_0")
+    a = ap.parse_args(argv)
+    import transformers
+    m = transformers.ViTForImageClassification.from_pretrained(a.model).eval()
+    hp = convert_hf_model(m, a.out, a.ftype)
+    print(f"wrote {a.out}: hidden {hp.hidden_size}, layers {hp.num_hidden_layers}, heads {hp.num_attention_heads}, classes {hp.num_classes}, patch {hp.patch_size}, img {hp.img_size}, ftype {a.ftype}")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
