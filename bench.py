@@ -167,6 +167,8 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(tf / PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_GB.get(dom["name"]), "traffic_unit": "GB per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_final_rocprofv3_summary.txt)",
                                "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "flops_per_launch": dom["flops"] / dom["launches"]}
+            if dom["name"] in ("gemm_fc2_resid", "gemm_proj_resid"):
+                out["roofline"]["traffic_note"] = "proj and fc2 run the same kernel symbols: the PMC figure is their mean per logical launch"
             out["roofline"]["launches_per_step"] = dom["launches"] / prof_steps
             out["roofline"]["measured_over"] = f"last {prof_steps} of the {args.steps} timed steps"
             out["roofline"]["schedule"] = "profiled steps: sub-batches serialised on one stream; other steps: 2 sub-batches on 2 HIP streams"
