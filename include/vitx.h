@@ -97,7 +97,9 @@ int vitx_preprocess_u8_device(const void *d_hwc, int n, int nx, int ny, int img_
 /* Uploads the weights to `device` in `dtype` and allocates all activation scratch
  * for up to max_batch images once (the reference reallocates per call, vit.cpp:1009-1035).
  * Contexts for >= 16 images cut every batch into 2 contiguous sub-batches that run on two
- * internal HIP streams (env VITX_STREAMS=1..4 overrides); results do not depend on it. */
+ * internal HIP streams (env VITX_STREAMS=1..4 overrides); the cut is placed where the GEMM tile
+ * counts of both parts fill whole rounds of CUs (110 + 146 for 256 ViT-B images on 256 CUs).
+ * Results do not depend on the split: images are independent in every kernel. */
 int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out);
 void vitx_ctx_free(vitx_ctx *c);
 int vitx_ctx_max_batch(const vitx_ctx *c);

@@ -95,7 +95,7 @@ def test_batch_independence_and_padding(pkg, binding, torch_gpu):
 
 
 def test_large_batch_kernels_agree_with_small_batch_kernels(pkg, binding, torch_gpu):
-    """ViT-B/16 at batch 203 (ragged: 2 sub-batches of 102/101 images, 256x256 persistent-stream GEMM tiles with a
+    """ViT-B/16 at batch 203 (ragged: 2 sub-batches cut by the tile-round model, 256x256 persistent-stream GEMM tiles with a
     partial last row tile + the 128x256 tail launch) must reproduce what the small-batch kernels (128x256 tiles, one
     stream) compute for the same images: every kernel consumes K in the same order, so the result is bit-identical."""
     name = "vit_base_patch16_224"

@@ -227,7 +227,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     const size_t hcols = std::max<size_t>((size_t)4 * D, (size_t)c->Kpe_pad);
     for (int i = 0; i < ns; ++i) {
         vitx_ctx::Slice &sl = c->slices[i];
-        sl.cap = ns > 1 ? max_batch : max_batch;     // every slice can hold the whole batch: the split point is chosen per call (split_batch)
+        sl.cap = max_batch;     // every slice can hold the whole batch: the split point is chosen per call (split_batch)
         const size_t Mpad = (size_t)round_up(sl.cap * c->N, c->tm), Bpad = (size_t)round_up(sl.cap, c->tm);
         if ((rc = c->dmalloc((void **)&sl.X, Mpad * D * 4, true))) return rc;
         if ((rc = c->dmalloc(&sl.U, Mpad * D * 2, true))) return rc;
