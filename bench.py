@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=8)
+    ap.add_argument("--cpu-images", type=int, default=48, help="images of the batch timed through the CPU oracle (~10-15 s on the 128-thread GPU host)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--ftype", default="f16", choices=["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"], help="weight file type (BASELINE config 5: q4_0)")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the secondary u8-from-host measurement")
