@@ -224,3 +224,40 @@ def test_bench_rccl_path_single_rank(torch_gpu):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "images/s" and d["scaling"] == "weak"
+
+
+def test_cli_prints_topk_like_the_reference_and_walks_a_directory(pkg, binding, oracle, torch_gpu, tmp_path):
+    """vit_cli.py (= main.cpp + the accuracy harness): stdout lines ' > label : 0.xx' (vit.cpp:1062-1067) for the bundled
+    tench.jpg agree with the oracle's top-5; --dir mode scores <label>/<image> trees."""
+    import shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = pkg.synth.cached_synthetic("vit_tiny_patch16_224", head_scale=4.0)
+    img = os.path.join(root, "tests", "golden", "assets", "tench.jpg")
+    r = subprocess.run([sys.executable, os.path.join(root, "vit_cli.py"), "-m", path, "-i", img, "-k", "5", "-t", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith(" > ")]
+    assert len(lines) == 5
+    from PIL import Image
+    u8 = np.asarray(Image.open(img).convert("RGB"), dtype=np.uint8)
+    _, rp = oracle.OracleModel(path).forward(oracle.preprocess(u8, 224, "bicubic")[None], oracle.REF)
+    order = np.argsort(-rp[0], kind="stable")[:5]
+    m = binding.Model(path)
+    for l, i in zip(lines, order):
+        label, prob = l[3:].rsplit(" : ", 1)
+        assert label == m.label(int(i)) and abs(float(prob) - rp[0][i]) <= 0.011      # 2 printed decimals
+    assert "model load time" in r.stderr and "loaded image" in r.stderr
+    # failure paths keep the reference's exit code 1 (main.cpp:57-61, 69-73)
+    assert subprocess.run([sys.executable, os.path.join(root, "vit_cli.py"), "-m", str(tmp_path / "none.gguf"), "-i", img], capture_output=True, text=True).returncode == 1
+    assert subprocess.run([sys.executable, os.path.join(root, "vit_cli.py"), "-m", path, "-i", str(tmp_path / "none.jpg")], capture_output=True, text=True).returncode == 1
+    # accuracy harness: put each asset under the label the model itself predicts for it -> 100 % by construction, except one planted miss
+    assets = sorted(os.listdir(os.path.join(root, "tests", "golden", "assets")))[:4]
+    ctx = binding.Context(m, max_batch=4, dtype=binding.F16)
+    pre = np.stack([binding.preprocess(np.asarray(Image.open(os.path.join(root, "tests", "golden", "assets", a)).convert("RGB"), dtype=np.uint8), 224) for a in assets])
+    pred = ctx.forward(pre).argmax(1)
+    for k, (a, p) in enumerate(zip(assets, pred)):
+        lab = m.label(int(p)) if k else m.label(int((p + 1) % 1000))          # first image filed under a wrong label
+        os.makedirs(tmp_path / "val" / lab, exist_ok=True)
+        shutil.copy(os.path.join(root, "tests", "golden", "assets", a), tmp_path / "val" / lab / a)
+    r = subprocess.run([sys.executable, os.path.join(root, "vit_cli.py"), "-m", path, "--dir", str(tmp_path / "val"), "--batch", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "top-1 accuracy: 0.7500 (3/4)" in r.stdout
