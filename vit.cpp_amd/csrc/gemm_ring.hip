@@ -250,7 +250,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
             for (int q = 0; q < (WMT + WNT) / RING_SCHED; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, RING_SCHED, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, WMT * WNT - 1 - (WMT + WNT) / RING_SCHED, 0);
+            if constexpr (WMT * WNT - 1 - (WMT + WNT) / RING_SCHED > 0) __builtin_amdgcn_sched_group_barrier(0x008, WMT * WNT - 1 - (WMT + WNT) / RING_SCHED, 0);
 #endif
         }
         // slot i+2 must have landed before the next iteration's prefetch of it; later slots stay in flight
@@ -438,6 +438,7 @@ static bool parse_cfg(int cfg, RingCfg &c) {
     c.wnt = 2; c.nwm = 2;
     if (c.ks == 2 && (cfg == 165 || cfg == 164)) { c.wmt = 2; c.nwm = 4; c.nwn = 4; return true; }
     if (c.ks == 2 && cfg == 945) { c.wmt = 4; c.nwn = 4; c.ns = 5; return true; }   // persistent stream kernel, 445 geometry
+    if (c.ks == 2 && cfg == 122) { c.wmt = 1; c.nwn = 2; c.ns = 5; return true; }   // skinny: 4 waves, tile 64x128, 60 KiB ring, 2 workgroups/CU (latency of tiny batches)
     return c.ks == 2 && (cfg == 445 || cfg == 245);
 }
 
@@ -477,6 +478,7 @@ static hipError_t launch_ring_e(const GemmArgs &a, int cfg, hipStream_t stream) 
     case 945: if constexpr (!DBG) return launch_stream_inst<T, EPI>(a, stream); else return hipErrorInvalidValue;
     case 445: return launch_ring_inst<T, EPI, 4, 2, 2, 4, 5, 2, DBG>(a, stream);
     case 245: return launch_ring_inst<T, EPI, 2, 2, 2, 4, 5, 2, DBG>(a, stream);
+    case 122: return launch_ring_inst<T, EPI, 1, 2, 2, 2, 5, 2, DBG>(a, stream);
     case 165: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 5, 2, DBG>(a, stream);      // 16 waves (4 per SIMD), 64x64 per wave, tile 256x256
     case 164: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 4, 2, DBG>(a, stream);
     default: return hipErrorInvalidValue;

@@ -188,6 +188,10 @@ hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream
         // 128x256 tiles for short M (e.g. the classifier head) -- measured in profiles/r01_gemm_configs.txt
         const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
         cfg = (a.M % 256 == 0 && t256 >= 128) ? 445 : 245;
+        // a handful of images: 128x256 tiles would leave most CUs idle behind a serial K loop; 64x128 tiles (same K order per
+        // element, so bit-identical results) spread the same work over 8x the workgroups
+        static const bool skinny_on = getenv("VITX_GEMM_NOSKINNY") == nullptr;
+        if (cfg == 245 && skinny_on && (long)(a.M / 128) * (a.N_pad / 256) < 64 && gemm_ring_supports(a, 122)) cfg = 122;
     }
     if (cfg == 945 && !gemm_ring_supports(a, 945)) cfg = gemm_ring_supports(a, 445) ? 445 : 245;
     // Tail split: one 256x256 tile per CU per round means e.g. 591 tiles (N = 768) cost 3 rounds for 2.31 rounds of
