@@ -192,21 +192,23 @@ def test_large_384_long_sequence_smoke(pkg, binding, oracle, torch_gpu):
     assert np.abs(logits - rl).max() <= 2.5e-2
 
 
-def test_quantised_file_runs_dequantised(pkg, binding, oracle, torch_gpu, tmp_path):
-    """BASELINE.json config 5 input format: a q4_0 file loads and runs (weights dequantised to fp16 at upload --
-    the dequant-in-LDS kernel is a later round); result must match the oracle run on the SAME dequantised weights
-    with fp16 activations (quant_act=0), i.e. the only difference from ggml is its q8_0 activation quantisation."""
+@pytest.mark.parametrize("ftype,tol_ggml", [(2, 2e-2), (3, 2e-2), (6, 1e-2), (7, 1e-2), (8, 5e-3)])
+def test_quantised_file_runs_dequantised(pkg, binding, oracle, torch_gpu, tmp_path, ftype, tol_ggml):
+    """BASELINE.json config 5 input format (q4_0) and the other block types (q4_1, q5_0, q5_1, q8_0): the file loads and
+    runs with its weights dequantised once at upload; the result must match the oracle run on the SAME dequantised weights
+    with fp16 activations (quant_act=0) to the north_star tolerance, i.e. the only difference from ggml is ggml's own q8_0 /
+    q8_1 quantisation of the ACTIVATIONS, whose effect on the probabilities is bounded by the stated looser tolerance."""
     import dataclasses
     name = "vit_tiny_patch16_224"
-    p = str(tmp_path / "q4.gguf")
-    pkg.synth.write_synthetic(p, name, ftype=2, head_scale=4.0)
+    p = str(tmp_path / "q.gguf")
+    pkg.synth.write_synthetic(p, name, ftype=ftype, head_scale=4.0)
     imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(3, 224))
     probs, logits = _run(binding, p, imgs, binding.F16)
     om = oracle.OracleModel(p)
     _, want = om.forward(imgs, dataclasses.replace(oracle.REF, quant_act=0))
     assert np.abs(probs - want).max() <= TOL_PROB
     _, ggml_sem = om.forward(imgs, oracle.REF)                # q8_0 activations like ggml: looser, stated tolerance
-    assert np.abs(probs - ggml_sem).max() <= 2e-2
+    assert np.abs(probs - ggml_sem).max() <= tol_ggml
     assert (probs.argmax(1) == ggml_sem.argmax(1)).all()
 
 
