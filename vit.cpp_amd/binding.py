@@ -108,7 +108,11 @@ class Model:
         if getattr(self, "_h", None) and self._h:
             lib().vitx_model_free(self._h); self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
     @property
     def num_classes(self) -> int: return self.hparams.num_classes
@@ -164,7 +168,11 @@ class Context:
         if getattr(self, "_h", None) and self._h:
             lib().vitx_ctx_free(self._h); self._h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def forward(self, imgs_hwc: np.ndarray, want_logits: bool = False):
         """Host arrays in/out (copies + sync): [n,S,S,3] f32 -> probs [n,C] (and logits)."""
