@@ -236,3 +236,36 @@ def test_gflop_accounting_matches_baseline_md(pkg):
     assert abs(pkg.synth.gflop_per_image(pkg.synth.hparams_for("vit_base_patch16_224")) - 35.1277) < 1e-3
     assert abs(pkg.synth.gflop_per_image(pkg.synth.hparams_for("vit_tiny_patch16_224")) - 2.5074) < 1e-3
     assert abs(pkg.synth.gflop_per_image(pkg.synth.hparams_for("vit_large_patch16_384")) - 382.1326) < 1e-3
+
+
+def _build_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "vit_main")
+    pkgdir = os.path.join(ROOT, "vit.cpp_amd")
+    cmd = ["g++", "-std=c++17", "-O1", os.path.join(ROOT, "examples", "vit_main.cpp"), "-I" + pkgdir, "-L" + pkgdir, "-lvitx", "-L/opt/rocm/lib",
+           "-Wl,-rpath," + pkgdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def test_cpp_example_main_compiles_against_the_drop_in_header(pkg, tmp_path):
+    """examples/vit_main.cpp = the reference's main.cpp flow on vit.cpp_amd/vit.h: it must compile and link with plain g++
+    (source compatibility of the mirror header), keep main.cpp's exit code 1 for a missing model / image (main.cpp:57-73),
+    and -- on a box without a GPU -- fail loudly at vit_predict instead of falling back to anything."""
+    import subprocess
+    exe = _build_example(tmp_path)
+    r = subprocess.run([exe, "-m", str(tmp_path / "none.gguf"), "-i", "x.ppm"], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed to load model" in r.stderr
+    model = pkg.synth.cached_synthetic("vit_micro_patch16_64", head_scale=4.0)
+    r = subprocess.run([exe, "-m", model, "-i", str(tmp_path / "none.ppm")], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed to load image" in r.stderr
+    ppm = tmp_path / "img.ppm"
+    rng = np.random.default_rng(3)
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n# comment line\n40 30\n255\n"); f.write(rng.integers(0, 256, size=(30, 40, 3), dtype=np.uint8).tobytes())
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, "-m", model, "-i", str(ppm)], capture_output=True, text=True)
+        assert r.returncode == 1 and "loaded image" in r.stderr and "(40 x 30)" in r.stderr
+        assert "no HIP device" in r.stderr or "HIP" in r.stderr

@@ -263,3 +263,33 @@ def test_cli_prints_topk_like_the_reference_and_walks_a_directory(pkg, binding, 
     r = subprocess.run([sys.executable, os.path.join(root, "vit_cli.py"), "-m", path, "--dir", str(tmp_path / "val"), "--batch", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "top-1 accuracy: 0.7500 (3/4)" in r.stdout
+
+
+def test_cpp_example_main_runs_like_the_reference_cli(pkg, binding, oracle, torch_gpu, tmp_path):
+    """examples/vit_main.cpp built with g++ against vit.cpp_amd/vit.h + libvitx.so: the reference's main.cpp flow end to end
+    (vit_params_parse, vit_model_load, vit_image_preprocess, vit_predict) on tench.jpg converted to PPM; its ' > label : p'
+    lines agree with the oracle's top-5."""
+    import subprocess
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkgdir = os.path.join(root, "vit.cpp_amd")
+    exe = str(tmp_path / "vit_main")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(root, "examples", "vit_main.cpp"), "-I" + pkgdir, "-L" + pkgdir, "-lvitx", "-L/opt/rocm/lib",
+                        "-Wl,-rpath," + pkgdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    u8 = np.asarray(Image.open(os.path.join(root, "tests", "golden", "assets", "tench.jpg")).convert("RGB"), dtype=np.uint8)
+    ppm = tmp_path / "tench.ppm"
+    with open(ppm, "wb") as f:
+        f.write(f"P6\n{u8.shape[1]} {u8.shape[0]}\n255\n".encode()); f.write(u8.tobytes())
+    path = pkg.synth.cached_synthetic("vit_tiny_patch16_224", head_scale=4.0)
+    r = subprocess.run([exe, "-m", path, "-i", str(ppm), "-k", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith(" > ")]
+    assert len(lines) == 5
+    _, rp = oracle.OracleModel(path).forward(oracle.preprocess(u8, 224, "bicubic")[None], oracle.REF)
+    order = np.argsort(-rp[0], kind="stable")[:5]
+    m = binding.Model(path)
+    for l, i in zip(lines, order):
+        label, prob = l[3:].rsplit(" : ", 1)
+        assert label == m.label(int(i)) and abs(float(prob) - rp[0][i]) <= 0.011
+    assert "processed, out dims : (224 x 224)" in r.stderr and "total time" in r.stderr
