@@ -1,0 +1,436 @@
+// gemm_pp.hip -- "ping-pong" persistent MFMA GEMM for gfx950: the wide-tile kernel of the ViT forward path.
+//
+//   C[M][N] = A[M][K] . W[N][K]^T  (+ fused epilogue), A/W fp16 or bf16, f32 accumulate
+//   (ggml_mul_mat at /root/reference/vit.cpp:772,820,868,889,896 with the bias / GELU / residual / pos-embed ops fused).
+//
+// Structure (DESIGN.md "GEMM"):
+//   * 512 threads = 8 waves as 2(M) x 4(N); tile 256x256, BK = 64; each wave owns 128x64 of C as 4x2 MFMA 32x32x16
+//     accumulators.  One persistent workgroup per CU walks its tiles and keeps ONE operand stream running across tile
+//     boundaries.
+//   * The two wave rows (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART ("ping-pong"): while one
+//     group issues its 8 MFMAs of a phase, the other issues its LDS fragment reads and LDS-DMA for its own phase, so
+//     every SIMD always has one wave in the matrix pipe and one in the memory pipes.  s_setprio(1) brackets the MFMAs.
+//   * A K-tile is 4 phases, one C quadrant (64x32 per wave, K = 64 -> 8 MFMAs) each, in the snake order
+//     C00, C01, C11, C10 so every operand fragment is read from LDS exactly once: 12 / 4 / 8 / 0 ds_read_b128.
+//   * LDS = 2 buffers x [A0 | A1 | B0 | B1] half-tiles of 16 KiB (128 rows x 128 B).  "A0" holds, for both wave rows,
+//     the first 64 of the wave's 128 rows (B0: for the four wave columns, the first 32 of the wave's 64 columns), so a
+//     half-tile is read in exactly one phase and can be re-staged two phases later.  One half-tile is staged per
+//     phase by LDS-DMA (global_load_lds dwordx4, 2 per thread), 5 phases ahead of its first read; a counted
+//     s_waitcnt vmcnt(8) per phase leaves the four youngest stages in flight across the raw s_barriers.
+//   * 128-B LDS rows, two rows per 256-B bank line, 16-B slots XOR-ed with (line & 15): conflict-free ds_read_b128;
+//     the DMA image is lane-linear, so the permutation is applied to the per-lane global SOURCE address.
+//   * Products are "swapped" (mfma(W fragment, A fragment)): each lane ends up with ONE row of C and 4 consecutive
+//     columns per accumulator group, so the epilogue moves 8/16 contiguous bytes per lane per store instead of 2.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace vitx {
+
+namespace pp {
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF = 16384;             // one half-tile image: 128 rows x 128 B
+constexpr int BUF = 4 * HALF;           // [A0 | A1 | B0 | B1]
+constexpr int LDS = 2 * BUF;            // 128 KiB
+constexpr int GROUP_M = 8;
+constexpr int STAGE_OPS = 2;            // LDS-DMA instructions per thread per half-tile
+constexpr int LEAD = 4;                 // stages allowed in flight past a phase's wait
+}  // namespace pp
+
+template <int N> __device__ __forceinline__ void pp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// ---- epilogue of one wave's 128 x 64 block.  Swapped-product C layout: lane -> row l31 of each 32-row block,
+// register r -> column (r&3) + 8*(r>>2) + 4*(lane>>5) of each 32-column block.
+template <typename T, int EPI, bool FULL>
+__device__ __forceinline__ void pp_epilogue(const GemmArgs &g, f32x16 (&acc)[4][2], int row0 /* + i*32 */, int ncol /* wave-uniform first column */, int hh) {
+    typedef typename Elem<T>::v4 v4;
+    typedef const __attribute__((address_space(4))) float *cptr;     // constant address space: wave-uniform -> s_load (no vmcnt traffic)
+    const int col0 = ncol + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            // bias of the 8 columns of this accumulator group: lanes 0-31 take the first four, lanes 32-63 the last four
+            // (the bias buffer is padded to the N tile, so reads beyond N stay inside it)
+            cptr cb = (cptr)(g.bias + ncol + j * 32 + rg * 8);
+            f32x4 bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float lo = cb[e], hi = cb[4 + e]; bv[e] = hh ? hi : lo; }
+            const int c = col0 + j * 32 + rg * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + i * 32;
+                const bool ok = FULL || (row < g.M_real && c < g.N);         // N % 4 == 0: a 4-column group is all in or all out
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + bv[e];
+                if constexpr (EPI == EPI_BIAS) {
+                    if (ok) *(v4 *)((T *)g.out + (size_t)row * g.ldo + c) = __builtin_convertvector(v, v4);
+                } else if constexpr (EPI == EPI_BIAS_GELU) {
+                    // bias, round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
+                    const typename Pair<T>::v2 x01 = round_pair<T>(v[0], v[1]), x23 = round_pair<T>(v[2], v[3]);
+                    const f32x2 y01 = gelu_tanh2(f32x2{(float)x01[0], (float)x01[1]}), y23 = gelu_tanh2(f32x2{(float)x23[0], (float)x23[1]});
+                    const typename Pair<T>::v2 o01 = round_pair<T>(y01[0], y01[1]), o23 = round_pair<T>(y23[0], y23[1]);
+                    if (ok) *(v4 *)((T *)g.out + (size_t)row * g.ldo + c) = v4{o01[0], o01[1], o23[0], o23[1]};
+                } else if constexpr (EPI == EPI_BIAS_RESID) {
+                    if (ok) { f32x4 *p = (f32x4 *)((float *)g.out + (size_t)row * g.ldo + c); *p = v + *p; }
+                } else if constexpr (EPI == EPI_BIAS_F32) {
+                    if (ok) *(f32x4 *)((float *)g.out + (size_t)row * g.ldo + c) = v;
+                } else {   // EPI_PATCH: patch row -> token row (+1 per image for the cls slot), + pos_embed
+                    if (ok) {
+                        const int b = row / g.tpi, t = row - b * g.tpi;
+                        const f32x4 pe = *(const f32x4 *)(g.pos + (size_t)(t + 1) * g.ldo + c);
+                        *(f32x4 *)((float *)g.out + ((size_t)row + b + 1) * g.ldo + c) = v + pe;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- full-tile epilogue with an EXACT number of vector-memory instructions (pp_epi_stores): every store is one
+// buffer_store_dwordx4 issued unconditionally, so the K loop of the next tile can skip over them with a counted vmcnt
+// instead of draining them (the stores of a 256x256 tile take ~8 us to retire when every CU stores at once).
+// 16-bit outputs: lanes l and l+32 hold columns 4hh..4hh+3 of each 8-column group; one v_permlane32_swap per dword
+// turns two groups into 8 contiguous columns per lane -> 16-byte stores.
+template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int EPI>
+__device__ __forceinline__ void pp_epilogue_full(const GemmArgs &g, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t ro, int voff, int soff, int soff_step /* 32 rows */, int ncol, int hh) {
+    typedef const __attribute__((address_space(4))) float *cptr;     // constant address space: wave-uniform -> s_load (no vmcnt traffic)
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        typedef typename Pair<T>::v2 v2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                cptr cb = (cptr)(g.bias + ncol + j * 32 + pr * 16);
+                float bA[4], bB[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float a0 = cb[e], a1 = cb[4 + e], b0 = cb[8 + e], b1 = cb[12 + e]; bA[e] = hh ? a1 : a0; bB[e] = hh ? b1 : b0; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float vA[4], vB[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vA[e] = acc[i][j][pr * 8 + e] + bA[e]; vB[e] = acc[i][j][pr * 8 + 4 + e] + bB[e]; }
+                    v2 pA0 = round_pair<T>(vA[0], vA[1]), pA1 = round_pair<T>(vA[2], vA[3]), pB0 = round_pair<T>(vB[0], vB[1]), pB1 = round_pair<T>(vB[2], vB[3]);
+                    if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
+                        const f32x2 yA0 = gelu_tanh2(f32x2{(float)pA0[0], (float)pA0[1]}), yA1 = gelu_tanh2(f32x2{(float)pA1[0], (float)pA1[1]});
+                        const f32x2 yB0 = gelu_tanh2(f32x2{(float)pB0[0], (float)pB0[1]}), yB1 = gelu_tanh2(f32x2{(float)pB1[0], (float)pB1[1]});
+                        pA0 = round_pair<T>(yA0[0], yA0[1]); pA1 = round_pair<T>(yA1[0], yA1[1]); pB0 = round_pair<T>(yB0[0], yB0[1]); pB1 = round_pair<T>(yB1[0], yB1[1]);
+                    }
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pA0), __builtin_bit_cast(unsigned, pB0), false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pA1), __builtin_bit_cast(unsigned, pB1), false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, ro, voff + (j * 64 + pr * 32), soff + i * soff_step, 0);
+                }
+            }
+    } else {       // f32 outputs: 4 consecutive columns per lane and group -> 16-byte stores (and loads, for the residual)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x4 res[2][2][4];
+            if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) res[ii][j][rg] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + (j * 128 + rg * 32), soff + (half * 2 + ii) * soff_step, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    cptr cb = (cptr)(g.bias + ncol + j * 32 + rg * 8);
+                    float bv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float lo = cb[e], hi = cb[4 + e]; bv[e] = hh ? hi : lo; }
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int i = half * 2 + ii;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + bv[e];
+                        if constexpr (EPI == EPI_BIAS_RESID) v = v + __builtin_bit_cast(f32x4, res[ii][j][rg]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, voff + (j * 128 + rg * 32), soff + i * soff_step, 0);
+                    }
+                }
+        }
+    }
+}
+
+// FLAGS (experiments, tools/gemm_lab): 1 = no s_setprio around the MFMAs, 2 = both wave rows in lock-step (no ping-pong),
+// 512 = epilogue stores drained (no counted skip), 4 = no LDS-DMA in the loop, 8 = no fragment reads, 16 = no MFMAs, 32 = s_memtime stamp after every barrier of K-tiles 4..7 of
+// the first tile (written to g.pos as [block][wave][64] u32)
+template <typename T, int EPI, int FLAGS>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
+    using namespace pp;
+    typedef typename Elem<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;            // wave row (= ping-pong group) / wave column
+
+    // ---- tile walk: virtual id v keeps v % 8 == bid % 8 (same XCD), then the XCD-contiguous GROUP_M raster
+    const int ntm = g.M / BM, ntn = g.N_pad / BN, ntiles = ntm * ntn;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int my_tiles = (ntiles - bid + nblk - 1) / nblk;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7;
+    const int lid_base = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8);
+    auto tile_origin = [&](int round, int &m0, int &n0) {
+        const int v = bid + round * nblk;
+        const int lid = lid_base + (v >> 3);
+        const int per_group = GROUP_M * ntn;
+        const int grp = lid / per_group, within = lid - grp * per_group;
+        const int gm = min(GROUP_M, ntm - grp * GROUP_M);
+        const int tn = within / gm;
+        m0 = (grp * GROUP_M + (within - tn * gm)) * BM; n0 = tn * BN;
+    };
+    if (my_tiles <= 0) return;
+
+    // ---- LDS-DMA: physical 16-B piece p = i*512 + tid of a half-tile image <-> logical (image row, slot)
+    const T *A = (const T *)g.A, *W = (const T *)g.W;
+    int aoff[STAGE_OPS], woff[STAGE_OPS];
+#pragma unroll
+    for (int i = 0; i < STAGE_OPS; ++i) {
+        int rr, sl; swz_inv(i * 512 + tid, rr, sl);
+        aoff[i] = ((rr >> 6) * 128 + (rr & 63)) * g.lda + sl * 8;      // image row -> tile row of half 0 (half 1: + 64 rows)
+        woff[i] = ((rr >> 5) * 64 + (rr & 31)) * g.ldw + sl * 8;       // image row -> tile column of half 0 (half 1: + 32 columns)
+    }
+    const int a_half = 64 * g.lda, w_half = 32 * g.ldw;
+    const int nkt = g.K / BK;                       // K-tiles per tile (even)
+
+    // issue side: K-tile `is_kt` of tile round `is_round`; half-tiles go out in the order A0, B0, B1, A1
+    int is_round = 0, is_kt = 0, is_a = 0, is_w = 0;
+    { int m0, n0; tile_origin(0, m0, n0); is_a = m0 * g.lda; is_w = n0 * g.ldw; }
+    // LDS-DMA through buffer_load ... lds: SRD + 32-bit per-lane byte offset + SGPR offset, so a stage costs two SALU adds and no VALU
+    // (global_load_lds with 64-bit per-lane addresses, FLAGS 256, made the stage issue 2.5x slower: profiles/r02_gemm_pp_lab.txt)
+    __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void *)A, 0, (int)0xffffffffu, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void *)W, 0, (int)0xffffffffu, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrcO = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)0xffffffffu, 0x00020000);
+    auto stage_a = [&](int h, int lds_off) {
+        char *base = smem + lds_off + wave * 1024;
+        if constexpr ((FLAGS & 256) == 0) {
+            const int so = (is_a + is_kt * BK + h * a_half) * 2;
+#pragma unroll
+            for (int i = 0; i < STAGE_OPS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, LPTR(base + i * 8192), 16, aoff[i] * 2, so, 0, 0);
+        } else {
+            const T *src = A + is_a + is_kt * BK + h * a_half;
+#pragma unroll
+            for (int i = 0; i < STAGE_OPS; ++i) __builtin_amdgcn_global_load_lds(GPTR(src + aoff[i]), LPTR(base + i * 8192), 16, 0, 0);
+        }
+    };
+    auto stage_w = [&](int h, int lds_off) {
+        char *base = smem + lds_off + wave * 1024;
+        if constexpr ((FLAGS & 256) == 0) {
+            const int so = (is_w + is_kt * BK + h * w_half) * 2;
+#pragma unroll
+            for (int i = 0; i < STAGE_OPS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, LPTR(base + i * 8192), 16, woff[i] * 2, so, 0, 0);
+        } else {
+            const T *src = W + is_w + is_kt * BK + h * w_half;
+#pragma unroll
+            for (int i = 0; i < STAGE_OPS; ++i) __builtin_amdgcn_global_load_lds(GPTR(src + woff[i]), LPTR(base + i * 8192), 16, 0, 0);
+        }
+    };
+    // after the A1 stage of a K-tile.  Past the end of the workgroup's stream the issue side stays on the last K-tile:
+    // those stages re-read valid memory into LDS regions that are never read again, which keeps ONE branch-free
+    // K-tile body with uniform wait counts (a peeled tail copy made hipcc spill ~230 registers).
+    const int last_round = my_tiles - 1;
+    auto advance = [&]() {
+        if (is_kt + 1 < nkt) ++is_kt;
+        else if (is_round < last_round) {
+            is_kt = 0; ++is_round;
+            int m0, n0; tile_origin(is_round, m0, n0); is_a = m0 * g.lda; is_w = n0 * g.ldw;
+        }
+    };
+
+    // ---- fragment read addresses (bytes within a buffer): A rows wr*64 + ii*32 + l31 of half-tile image, B rows wc*32 + l31
+    int rdA[4], rdB[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        rdA[ks] = swz_byte(wr * 64 + l31, ks * 2 + hh);
+        rdB[ks] = 2 * HALF + swz_byte(wc * 32 + l31, ks * 2 + hh);
+    }
+    v8 fa[2][4], fb[2][4];
+    f32x16 acc[4][2];
+    auto read_a = [&](int buf, int h) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = *(const v8 *)(smem + buf * BUF + h * HALF + ii * 4096 + rdA[ks]);
+    };
+    auto read_b = [&](int buf, int h) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb[h][ks] = *(const v8 *)(smem + buf * BUF + h * HALF + rdB[ks]);
+    };
+    auto mma = [&](int ha, int hb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) acc[2 * ha + ii][hb] = Elem<T>::mfma(fb[hb][ks], fa[ii][ks], acc[2 * ha + ii][hb]);
+    };
+    unsigned stamps = 0; int n_stamp = -1;          // timeline experiment: lane i of `stamps` = i-th stamp
+    auto stamp = [&]() {
+        if constexpr ((FLAGS & 32) != 0) {
+            if (n_stamp >= 0 && n_stamp < 64) {
+                const unsigned t = (unsigned)__builtin_readcyclecounter();
+                stamps = lane == n_stamp ? t : stamps;
+                ++n_stamp;
+            }
+        }
+    };
+    auto fine_stamp = [&]() {                       // FLAGS 64: five stamps per phase (after B2, after the stage issue, after the vmcnt wait, after B1 + reads landed, after the MFMAs)
+        if constexpr ((FLAGS & 64) != 0) {
+            if (n_stamp >= 0 && n_stamp < 64) {
+                const unsigned t = (unsigned)__builtin_readcyclecounter();
+                stamps = lane == n_stamp ? t : stamps;
+                ++n_stamp;
+            }
+        }
+    };
+    // one phase = [reads, stage] | counted wait | barrier | 8 MFMAs | barrier
+#define PP_PHASE(READS, STAGE, VMCNT, HA, HB, RLX)                                              \
+    {                                                                                      \
+        if constexpr ((FLAGS & (64 | 128)) != 0) {                                         \
+            if (!(FLAGS & 4)) { STAGE; }                                                   \
+            fine_stamp();                                                                  \
+            pp_wait_vmcnt<VMCNT>();                                                        \
+            fine_stamp();                                                                  \
+            if (!(FLAGS & 8)) { READS; }                                                   \
+        } else {                                                                           \
+            if (!(FLAGS & 8)) { READS; }                                                   \
+            if (!(FLAGS & 4)) { STAGE; }                                                   \
+            if (RLX) pp_wait_vmcnt<VMCNT + pp_epi_stores<EPI>()>(); else pp_wait_vmcnt<VMCNT>();   \
+        }                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        pp_barrier();                                                                      \
+        stamp(); fine_stamp();                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(1);                                   \
+        if (!(FLAGS & 16)) mma(HA, HB);                                                    \
+        if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(0);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        fine_stamp();                                                                      \
+        pp_barrier();                                                                      \
+        stamp(); fine_stamp();                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+    // `relaxed`: the first K-tile after a full-tile epilogue -- its stores are younger than the stages these four waits
+    // retire, so the count skips over exactly pp_epi_stores() of them instead of draining them.
+    bool relaxed = false;
+    auto ktile = [&](auto bc) {
+        constexpr int B = decltype(bc)::value;       // buffer of the K-tile being consumed
+        constexpr int O = (B ^ 1) * BUF, S = B * BUF, W8 = LEAD * STAGE_OPS;
+        const bool rlx = B == 0 && relaxed;
+        PP_PHASE((read_a(B, 0), read_b(B, 0)), stage_w(1, O + 3 * HALF), W8, 0, 0, rlx)                    // C00 ; B1 of the next K-tile
+        PP_PHASE(read_b(B, 1), (stage_a(1, O + 1 * HALF), advance()), W8, 0, 1, rlx)                        // C01 ; A1 of the next K-tile
+        PP_PHASE(read_a(B, 1), stage_a(0, S + 0 * HALF), W8, 1, 1, rlx)                                     // C11 ; A0 two K-tiles ahead
+        PP_PHASE((void)0, stage_w(0, S + 2 * HALF), W8, 1, 0, rlx)                                          // C10 ; B0 two K-tiles ahead
+        if (B == 0) relaxed = false;
+    };
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+
+    // ---- prologue: A0 B0 B1 A1 of K-tile 0 and A0 B0 of K-tile 1 in flight, the first two landed
+    stage_a(0, 0 * HALF); stage_w(0, 2 * HALF); stage_w(1, 3 * HALF); stage_a(1, 1 * HALF); advance();     // nkt >= 2: K-tile 1 exists
+    stage_a(0, BUF + 0 * HALF); stage_w(0, BUF + 2 * HALF);
+    pp_wait_vmcnt<4 * STAGE_OPS>();
+    pp_barrier();
+    if (!(FLAGS & 2) && wr == 1) pp_barrier();      // the second wave row runs one barrier behind the first
+
+    for (int round = 0; round < my_tiles; ++round) {
+        int m0, n0; tile_origin(round, m0, n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int kt = 0; kt < nkt; kt += 2) {
+            if constexpr ((FLAGS & (32 | 64)) != 0) { if (round == 0 && kt == 4) n_stamp = 0; }
+            ktile(I0{}); ktile(I1{});
+        }
+        if constexpr ((FLAGS & 8) != 0) {           // fragments never read: keep the MFMA operands "defined" for the compiler
+            if (round == 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(fa[ii][ks])); asm volatile("" : "+v"(fb[ii][ks])); } }
+        }
+        if constexpr ((FLAGS & 16) != 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" :: "v"(fa[ii][ks]), "v"(fb[ii][ks])); } }
+        const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
+        if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
+            constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
+            const int voff = ((wr * 128 + l31) * g.ldo + wc * 64 + hh * (esz == 2 ? 8 : 4)) * esz;
+            // readfirstlane: the tile origin comes out of an integer division done on the VALU; without it hipcc wraps every
+            // buffer op in a waterfall loop over the (uniform) SGPR offset
+            pp_epilogue_full<T, EPI>(g, acc, rsrcO, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 32 * g.ldo * esz, __builtin_amdgcn_readfirstlane(n0 + wc * 64), hh);
+            relaxed = true;
+        } else {
+            const int row0 = m0 + wr * 128 + l31, ncol = n0 + wc * 64;
+            if (full) pp_epilogue<T, EPI, true>(g, acc, row0, ncol, hh);
+            else pp_epilogue<T, EPI, false>(g, acc, row0, ncol, hh);
+        }
+    }
+    if (!(FLAGS & 2) && wr == 0) pp_barrier();
+    pp_wait_vmcnt<0>();                             // the trailing (unused) stages must land before the LDS allocation is released
+    if constexpr ((FLAGS & (32 | 64)) != 0) ((unsigned *)g.pos)[((size_t)bid * 8 + wave) * 64 + lane] = stamps;
+#undef PP_PHASE
+}
+
+bool gemm_pp_supports(const GemmArgs &a) {
+    // byte offsets into A, W and out are 32-bit (buffer addressing)
+    const size_t lim = 0xf0000000u;
+    if ((size_t)a.M * a.lda * 2 > lim || (size_t)a.N_pad * a.ldw * 2 > lim || (size_t)(a.M + a.M / 64 + 2) * a.ldo * 4 > lim) return false;
+    return a.M % pp::BM == 0 && a.N_pad % pp::BN == 0 && a.K % (2 * pp::BK) == 0 && a.K >= 2 * pp::BK && a.N % 4 == 0 && a.ldo % 4 == 0;
+}
+
+template <typename T, int EPI, int FLAGS>
+static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<T, EPI, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS);
+    const int ntiles = (a.M / pp::BM) * (a.N_pad / pp::BN);
+    int cap = n_cu & ~7;                             // the tile walk keeps a workgroup on one XCD: grid is a multiple of 8
+    if (cap <= 0) cap = 256;
+    const int grid = ntiles < cap ? ntiles : cap;
+    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI, FLAGS>), dim3(grid), dim3(512), pp::LDS, stream, a);
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags) {
+    if (flags) {       // experiment builds exist for the plain bias epilogue only
+        if (epi != EPI_BIAS) return hipErrorInvalidValue;
+        switch (flags) {
+        case 1: return launch_pp_inst<T, EPI_BIAS, 1>(a, n_cu, stream);
+        case 2: return launch_pp_inst<T, EPI_BIAS, 2>(a, n_cu, stream);
+        case 4: return launch_pp_inst<T, EPI_BIAS, 4>(a, n_cu, stream);
+        case 8: return launch_pp_inst<T, EPI_BIAS, 8>(a, n_cu, stream);
+        case 12: return launch_pp_inst<T, EPI_BIAS, 12>(a, n_cu, stream);
+        case 16: return launch_pp_inst<T, EPI_BIAS, 16>(a, n_cu, stream);
+        case 20: return launch_pp_inst<T, EPI_BIAS, 20>(a, n_cu, stream);
+        case 24: return launch_pp_inst<T, EPI_BIAS, 24>(a, n_cu, stream);
+        case 32: return launch_pp_inst<T, EPI_BIAS, 32>(a, n_cu, stream);
+        case 44: return launch_pp_inst<T, EPI_BIAS, 44>(a, n_cu, stream);
+        case 56: return launch_pp_inst<T, EPI_BIAS, 56>(a, n_cu, stream);
+        case 64: return launch_pp_inst<T, EPI_BIAS, 64>(a, n_cu, stream);
+        case 128: return launch_pp_inst<T, EPI_BIAS, 128>(a, n_cu, stream);
+        case 256: return launch_pp_inst<T, EPI_BIAS, 256>(a, n_cu, stream);
+        case 512: return launch_pp_inst<T, EPI_BIAS, 512>(a, n_cu, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    switch (epi) {
+    case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 0>(a, n_cu, stream);
+    case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 0>(a, n_cu, stream);
+    case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 0>(a, n_cu, stream);
+    case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 0>(a, n_cu, stream);
+    case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 0>(a, n_cu, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_gemm_pp(int dtype, int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags) {
+    if (!gemm_pp_supports(a)) return hipErrorInvalidValue;
+    return dtype == DT_F16 ? launch_pp_t<_Float16>(epi, a, n_cu, stream, flags) : launch_pp_t<__bf16>(epi, a, n_cu, stream, flags);
+}
+
+}  // namespace vitx
