@@ -15,12 +15,8 @@
 
 #include "../vit.cpp_amd/csrc/kernels.h"
 
-namespace vitx {
-hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream);
-hipError_t launch_gemm_pp(int dtype, int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags);
-bool gemm_pp_supports(const GemmArgs &a);
-}  // namespace vitx
 using namespace vitx;
+static const Tuning *g_tune = nullptr;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
@@ -71,7 +67,7 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
     unsigned *tl = nullptr;
     if (v.kind == 1 && (v.cfg & 96)) { CK(hipMalloc(&tl, 256 * 8 * 64 * 4)); CK(hipMemset(tl, 0, 256 * 8 * 64 * 4)); g.pos = (const float *)tl; }
     if (v.kind == 1 && (v.cfg & 28)) check = false;
-    auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(dtype, epi, g, v.cfg, 0) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
+    auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(*g_tune, dtype, epi, g, v.cfg, 0) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
 
     // ---- check first (on a fresh output buffer): 4096 sampled outputs incl. the corners of the first and last tile
     char verdict[96] = "unchecked";
@@ -152,6 +148,8 @@ int main(int argc, char **argv) {
     const char *filter = argc > 2 ? argv[2] : "";
     int n_cu = 256; (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0);
     if (const char *e = getenv("LAB_CUS")) n_cu = atoi(e);
+    g_tune = tuning_for_device(0);
+    if (!g_tune) { fprintf(stderr, "kernel bring-up failed\n"); return 2; }
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("# device %s, %d CUs, clock %d MHz; iters %d\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000, iters);
     const Shape shapes[] = {
@@ -160,7 +158,7 @@ int main(int argc, char **argv) {
         {"qkvL", 73984, 3072, 1024}, {"fc2L", 73984, 1024, 4096},
     };
     const Variant variants[] = {{"ring945", 0, 945}, {"pp", 1, 0}, {"pp_noprio", 1, 1}, {"pp_lock", 1, 2}, {"pp_nodma", 1, 4}, {"pp_noread", 1, 8}, {"pp_mfmaonly", 1, 12},
-                                {"pp_nomfma", 1, 16}, {"pp_readonly", 1, 20}, {"pp_dmaonly", 1, 24}, {"pp_stamp", 1, 32}, {"pp_mfmaonly_stamp", 1, 44}, {"pp_dmaonly_stamp", 1, 56}, {"pp_fine", 1, 64}, {"pp_stagefirst", 1, 128}, {"pp_glds", 1, 256}, {"pp_drain", 1, 512}};
+                                {"pp_nomfma", 1, 16}, {"pp_readonly", 1, 20}, {"pp_dmaonly", 1, 24}, {"pp_stamp", 1, 32}, {"pp_nodma_stamp", 1, 36}, {"pp_noread_stamp", 1, 40}, {"pp_mfmaonly_stamp", 1, 44}, {"pp_dmaonly_stamp", 1, 56}, {"pp_fine", 1, 64}, {"pp_stagefirst", 1, 128}, {"pp_glds", 1, 256}, {"pp_drain", 1, 512}};
     for (const Shape &sh : shapes)
         for (const Variant &v : variants) {
             int epis[4] = {EPI_BIAS, -1, -1, -1};

@@ -52,6 +52,9 @@ struct vitx_ctx {
     int device = 0, dtype = VITX_F16, max_batch = 0;
     int D = 0, L = 0, H = 0, C = 0, P = 0, S = 0, g = 0, N = 0, Kpe = 0, Kpe_pad = 0, C_pad = 0;
     int tm = 128, tn = 128;
+    const Tuning *tune = nullptr;        // per-device launch parameters (CU count, kernel selection), immutable
+    int split_override[4] = {0, 0, 0, 0};  // VITX_SPLIT, parsed at creation
+    bool slices_serial = false;          // VITX_SLICES_SERIAL, parsed at creation
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     // weights
@@ -159,7 +162,7 @@ int gemm(vitx_ctx *c, hipStream_t st, int pc, int epi, const void *A, const void
     double bytes = (double)M_real * K * 2 + (double)N * K * 2 + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
     ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
-    HIP_TRY(launch_gemm(c->dtype, epi, a, st));
+    HIP_TRY(launch_gemm(*c->tune, c->dtype, epi, a, st));
     return VITX_OK;
 }
 
@@ -184,7 +187,19 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     c->g = c->S / c->P; c->N = c->g * c->g + 1; c->Kpe = 3 * c->P * c->P; c->Kpe_pad = round_up(c->Kpe, 64);
     c->tm = gemm_tile_m(); c->tn = gemm_tile_n();
     c->C_pad = round_up(c->C, c->tn);
-    if ((c->N + 31) / 32 > 19) { set_error("vitx_ctx_create: %d tokens per image exceeds the single-pass attention kernel (max 608)", c->N); return VITX_ERR_UNSUPPORTED; }
+    // validate against what the kernels are actually instantiated for (a context that would fail on its first forward is refused here)
+    if (!attention_supports(c->N, c->D, c->H)) {
+        set_error("vitx_ctx_create: %d tokens per image (img_size %d, patch_size %d) is outside the fused attention kernel's instantiations (1-224, 225-256 and 577-608 tokens)", c->N, c->S, c->P);
+        return VITX_ERR_UNSUPPORTED;
+    }
+    if (!layernorm_supports(c->D)) { set_error("vitx_ctx_create: hidden_size %d has no LayerNorm instantiation (64, 128, 192, 256, 384, 512, 768, 1024, 1280, 1536)", c->D); return VITX_ERR_UNSUPPORTED; }
+    c->tune = tuning_for_device(device);
+    if (!c->tune) { set_error("vitx_ctx_create: kernel bring-up on device %d failed: %s", device, hipGetErrorString(hipGetLastError())); return VITX_ERR_HIP; }
+    if (const char *e = getenv("VITX_SPLIT")) {          // experiments: "110" or "110,110" = sizes of the first nslices-1 sub-batches
+        int i = 0;
+        for (const char *p = e; i < 3 && *p; ++i) { c->split_override[i] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+    }
+    c->slices_serial = getenv("VITX_SLICES_SERIAL") != nullptr;     // for rocprofv3 runs that should match the profiled steps
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
     const int D = c->D, tn = c->tn;
@@ -281,7 +296,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         if ((rc = gemm(c, st, PC_GEMM_QKV, EPI_BIAS, sl.U, w.qkv_w, w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
-            HIP_TRY(launch_attention(dt, sl.QKV, sl.U, n, N, D, c->H, st));
+            HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873)
         if ((rc = gemm(c, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, w.proj_w, w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4))) return rc;
@@ -327,21 +342,18 @@ static double gemm_round_cost(long rows, int N, int K, int n_cu) {
 static void split_batch(const vitx_ctx *c, int n, int ns, int *m) {
     const int base = n / ns, extra = n % ns;
     for (int i = 0; i < ns; ++i) m[i] = base + (i < extra ? 1 : 0);
-    if (const char *e = getenv("VITX_SPLIT")) {          // experiments: "110" or "110,110" = sizes of the first ns-1 sub-batches
+    if (c->split_override[0] > 0) {
         int left = n, i = 0;
-        for (const char *p = e; i < ns - 1 && *p; ++i) {
-            const int v = atoi(p);
+        for (; i < ns - 1; ++i) {
+            const int v = c->split_override[i];
             if (v <= 0 || v >= left) break;
             m[i] = v; left -= v;
-            while (*p && *p != ',') ++p;
-            if (*p == ',') ++p;
         }
         if (i == ns - 1) { m[ns - 1] = left; return; }
         for (int k = 0; k < ns; ++k) m[k] = base + (k < extra ? 1 : 0);
     }
     if (ns != 2) return;
-    static int n_cu = 0;
-    if (!n_cu) { (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device); if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = c->tune->n_cu;
     const int D = c->D;
     auto layer = [&](int imgs) {
         const long rows = (long)imgs * c->N;
@@ -361,8 +373,7 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     // while per-kernel profiling is on, sub-batches run back to back on the caller's stream so that every
     // event pair brackets one kernel running alone (exclusive durations, comparable with rocprofv3 --stats)
-    static const bool serial_env = getenv("VITX_SLICES_SERIAL") != nullptr;     // for rocprofv3 runs that should match the profiled steps
-    const bool serial = c->prof_on || serial_env;
+    const bool serial = c->prof_on || c->slices_serial;
     const int ns = (c->nslices > 1 && n >= 8 * c->nslices) ? c->nslices : 1;
     if (ns == 1) return forward_slice(c, c->slices[0], st, d_imgs, n, d_probs, d_logits);
     int m[4];
@@ -464,13 +475,17 @@ int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *b
     GemmArgs g{};
     g.A = a; g.W = w; g.bias = (const float *)bias; g.out = out; g.pos = nullptr;
     g.M = M; g.M_real = M; g.N = N; g.N_pad = round_up(N, gemm_tile_n()); g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = 0;
-    hipError_t e = launch_gemm(dtype, epi, g, (hipStream_t)stream);
+    const Tuning *t = tuning_for_device(-1);
+    if (!t) { set_error("vitx_op_gemm: kernel bring-up failed"); return VITX_ERR_HIP; }
+    hipError_t e = launch_gemm(*t, dtype, epi, g, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_gemm: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
     return VITX_OK;
 }
 int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
     if (!qkv || !out || n_img <= 0) return VITX_ERR_ARG;
-    hipError_t e = launch_attention(dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
+    const Tuning *t = tuning_for_device(-1);
+    if (!t) { set_error("vitx_op_attention: kernel bring-up failed"); return VITX_ERR_HIP; }
+    hipError_t e = launch_attention(*t, dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_attention: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
     return VITX_OK;
 }

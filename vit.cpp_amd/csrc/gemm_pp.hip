@@ -387,8 +387,11 @@ bool gemm_pp_supports(const GemmArgs &a) {
 }
 
 template <typename T, int EPI, int FLAGS>
-static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void *)gemm_pp_kernel<T, EPI, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS);
+static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream, bool prepare) {
+    if (prepare || FLAGS) {     // once per device (tuning_for_device); the experiment builds set it on every launch
+        hipError_t e = hipFuncSetAttribute((const void *)gemm_pp_kernel<T, EPI, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS);
+        if (prepare) return e;
+    }
     const int ntiles = (a.M / pp::BM) * (a.N_pad / pp::BN);
     int cap = n_cu & ~7;                             // the tile walk keeps a workgroup on one XCD: grid is a multiple of 8
     if (cap <= 0) cap = 256;
@@ -397,40 +400,42 @@ static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream
     return hipGetLastError();
 }
 template <typename T>
-static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags) {
+static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags, bool prepare) {
     if (flags) {       // experiment builds exist for the plain bias epilogue only
         if (epi != EPI_BIAS) return hipErrorInvalidValue;
         switch (flags) {
-        case 1: return launch_pp_inst<T, EPI_BIAS, 1>(a, n_cu, stream);
-        case 2: return launch_pp_inst<T, EPI_BIAS, 2>(a, n_cu, stream);
-        case 4: return launch_pp_inst<T, EPI_BIAS, 4>(a, n_cu, stream);
-        case 8: return launch_pp_inst<T, EPI_BIAS, 8>(a, n_cu, stream);
-        case 12: return launch_pp_inst<T, EPI_BIAS, 12>(a, n_cu, stream);
-        case 16: return launch_pp_inst<T, EPI_BIAS, 16>(a, n_cu, stream);
-        case 20: return launch_pp_inst<T, EPI_BIAS, 20>(a, n_cu, stream);
-        case 24: return launch_pp_inst<T, EPI_BIAS, 24>(a, n_cu, stream);
-        case 32: return launch_pp_inst<T, EPI_BIAS, 32>(a, n_cu, stream);
-        case 44: return launch_pp_inst<T, EPI_BIAS, 44>(a, n_cu, stream);
-        case 56: return launch_pp_inst<T, EPI_BIAS, 56>(a, n_cu, stream);
-        case 64: return launch_pp_inst<T, EPI_BIAS, 64>(a, n_cu, stream);
-        case 128: return launch_pp_inst<T, EPI_BIAS, 128>(a, n_cu, stream);
-        case 256: return launch_pp_inst<T, EPI_BIAS, 256>(a, n_cu, stream);
-        case 512: return launch_pp_inst<T, EPI_BIAS, 512>(a, n_cu, stream);
+        case 1: return launch_pp_inst<T, EPI_BIAS, 1>(a, n_cu, stream, prepare);
+        case 2: return launch_pp_inst<T, EPI_BIAS, 2>(a, n_cu, stream, prepare);
+        case 4: return launch_pp_inst<T, EPI_BIAS, 4>(a, n_cu, stream, prepare);
+        case 8: return launch_pp_inst<T, EPI_BIAS, 8>(a, n_cu, stream, prepare);
+        case 12: return launch_pp_inst<T, EPI_BIAS, 12>(a, n_cu, stream, prepare);
+        case 16: return launch_pp_inst<T, EPI_BIAS, 16>(a, n_cu, stream, prepare);
+        case 20: return launch_pp_inst<T, EPI_BIAS, 20>(a, n_cu, stream, prepare);
+        case 24: return launch_pp_inst<T, EPI_BIAS, 24>(a, n_cu, stream, prepare);
+        case 32: return launch_pp_inst<T, EPI_BIAS, 32>(a, n_cu, stream, prepare);
+        case 36: return launch_pp_inst<T, EPI_BIAS, 36>(a, n_cu, stream, prepare);
+        case 40: return launch_pp_inst<T, EPI_BIAS, 40>(a, n_cu, stream, prepare);
+        case 44: return launch_pp_inst<T, EPI_BIAS, 44>(a, n_cu, stream, prepare);
+        case 56: return launch_pp_inst<T, EPI_BIAS, 56>(a, n_cu, stream, prepare);
+        case 64: return launch_pp_inst<T, EPI_BIAS, 64>(a, n_cu, stream, prepare);
+        case 128: return launch_pp_inst<T, EPI_BIAS, 128>(a, n_cu, stream, prepare);
+        case 256: return launch_pp_inst<T, EPI_BIAS, 256>(a, n_cu, stream, prepare);
+        case 512: return launch_pp_inst<T, EPI_BIAS, 512>(a, n_cu, stream, prepare);
         default: return hipErrorInvalidValue;
         }
     }
     switch (epi) {
-    case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 0>(a, n_cu, stream);
-    case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 0>(a, n_cu, stream);
-    case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 0>(a, n_cu, stream);
-    case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 0>(a, n_cu, stream);
-    case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 0>(a, n_cu, stream);
+    case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 0>(a, n_cu, stream, prepare);
+    case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 0>(a, n_cu, stream, prepare);
+    case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 0>(a, n_cu, stream, prepare);
+    case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 0>(a, n_cu, stream, prepare);
+    case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 0>(a, n_cu, stream, prepare);
     default: return hipErrorInvalidValue;
     }
 }
-hipError_t launch_gemm_pp(int dtype, int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags) {
-    if (!gemm_pp_supports(a)) return hipErrorInvalidValue;
-    return dtype == DT_F16 ? launch_pp_t<_Float16>(epi, a, n_cu, stream, flags) : launch_pp_t<__bf16>(epi, a, n_cu, stream, flags);
+hipError_t launch_gemm_pp(int dtype, int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags, bool prepare) {
+    if (!prepare && !gemm_pp_supports(a)) return hipErrorInvalidValue;
+    return dtype == DT_F16 ? launch_pp_t<_Float16>(epi, a, n_cu, stream, flags, prepare) : launch_pp_t<__bf16>(epi, a, n_cu, stream, flags, prepare);
 }
 
 }  // namespace vitx

@@ -433,39 +433,35 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN * 64) / 256) void gemm_s
 // ---- configurations: cfg = WMT*100 + NWN*10 + NS
 struct RingCfg { int wmt, nwn, ns, ks, wnt, nwm; };
 static bool parse_cfg(int cfg, RingCfg &c) {
-    c.ks = cfg >= 1000 ? cfg / 1000 : 2; cfg %= 1000;
-    c.wmt = cfg / 100; c.nwn = (cfg / 10) % 10; c.ns = cfg % 10;
-    c.wnt = 2; c.nwm = 2;
-    if (c.ks == 2 && (cfg == 165 || cfg == 164)) { c.wmt = 2; c.nwm = 4; c.nwn = 4; return true; }
-    if (c.ks == 2 && cfg == 945) { c.wmt = 4; c.nwn = 4; c.ns = 5; return true; }   // persistent stream kernel, 445 geometry
-    if (c.ks == 2 && cfg == 122) { c.wmt = 1; c.nwn = 2; c.ns = 5; return true; }   // skinny: 4 waves, tile 64x128, 60 KiB ring, 2 workgroups/CU (latency of tiny batches)
-    return c.ks == 2 && (cfg == 445 || cfg == 245);
+    c.ks = 2; c.wnt = 2; c.nwm = 2; c.ns = 5;
+    switch (cfg) {
+    case 445: case 945: c.wmt = 4; c.nwn = 4; return true;      // 256x256, one workgroup per tile / persistent stream kernel
+    case 245: c.wmt = 2; c.nwn = 4; return true;                // 128x256
+    case 122: c.wmt = 1; c.nwn = 2; return true;                // skinny: 4 waves, tile 64x128, 60 KiB ring, 2 workgroups/CU (latency of tiny batches)
+    default: return false;
+    }
 }
 
 template <typename T, int EPI, int WMT, int WNT, int NWM, int NWN, int NS, int KS, bool DBG>
-static hipError_t launch_ring_inst(const GemmArgs &a, hipStream_t stream) {
+static hipError_t launch_ring_inst(const GemmArgs &a, hipStream_t stream, bool prepare) {
     constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32;
     constexpr int lds = NS * (BM + BN) * 32 * KS;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+    if (prepare || DBG) {       // once per device (tuning_for_device); the ablation builds set it on every launch
+        hipError_t e = hipFuncSetAttribute((const void *)gemm_ring_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (prepare) return e;
+    }
     const int grid = (a.M / BM) * (a.N_pad / BN);
     hipLaunchKernelGGL((gemm_ring_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS, DBG>), dim3(grid), dim3(NWM * NWN * 64), lds, stream, a);
     return hipGetLastError();
 }
 
 template <typename T, int EPI>
-static hipError_t launch_stream_inst(const GemmArgs &a, hipStream_t stream) {
+static hipError_t launch_stream_inst(const GemmArgs &a, int n_cu, hipStream_t stream, bool prepare) {
     constexpr int WMT = 4, WNT = 2, NWM = 2, NWN = 4, NS = 5, KS = 2;
     constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32, lds = NS * (BM + BN) * 32 * KS;
-    static bool attr_set = false;
-    static int n_cu = 0;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)gemm_stream_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (n_cu <= 0) n_cu = 256;
-        n_cu &= ~7;                                  // the tile walk keeps a workgroup on one XCD: grid must be a multiple of 8
-        attr_set = true;
-    }
+    if (prepare) return hipFuncSetAttribute((const void *)gemm_stream_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    n_cu &= ~7;                                      // the tile walk keeps a workgroup on one XCD: grid must be a multiple of 8
+    if (n_cu <= 0) n_cu = 256;
     const int ntiles = (a.M / BM) * (a.N_pad / BN);
     const int grid = ntiles < n_cu ? ntiles : n_cu;
     hipLaunchKernelGGL((gemm_stream_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS>), dim3(grid), dim3(NWM * NWN * 64), lds, stream, a);
@@ -473,26 +469,24 @@ static hipError_t launch_stream_inst(const GemmArgs &a, hipStream_t stream) {
 }
 
 template <typename T, int EPI, bool DBG>
-static hipError_t launch_ring_e(const GemmArgs &a, int cfg, hipStream_t stream) {
+static hipError_t launch_ring_e(const GemmArgs &a, int cfg, int n_cu, hipStream_t stream, bool prepare) {
     switch (cfg) {
-    case 945: if constexpr (!DBG) return launch_stream_inst<T, EPI>(a, stream); else return hipErrorInvalidValue;
-    case 445: return launch_ring_inst<T, EPI, 4, 2, 2, 4, 5, 2, DBG>(a, stream);
-    case 245: return launch_ring_inst<T, EPI, 2, 2, 2, 4, 5, 2, DBG>(a, stream);
-    case 122: return launch_ring_inst<T, EPI, 1, 2, 2, 2, 5, 2, DBG>(a, stream);
-    case 165: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 5, 2, DBG>(a, stream);      // 16 waves (4 per SIMD), 64x64 per wave, tile 256x256
-    case 164: return launch_ring_inst<T, EPI, 2, 2, 4, 4, 4, 2, DBG>(a, stream);
+    case 945: if constexpr (!DBG) return launch_stream_inst<T, EPI>(a, n_cu, stream, prepare); else return hipErrorInvalidValue;
+    case 445: return launch_ring_inst<T, EPI, 4, 2, 2, 4, 5, 2, DBG>(a, stream, prepare);
+    case 245: return launch_ring_inst<T, EPI, 2, 2, 2, 4, 5, 2, DBG>(a, stream, prepare);
+    case 122: return launch_ring_inst<T, EPI, 1, 2, 2, 2, 5, 2, DBG>(a, stream, prepare);
     default: return hipErrorInvalidValue;
     }
 }
 template <typename T>
-static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, hipStream_t stream) {
-    if (a.dbg) return epi == EPI_BIAS ? launch_ring_e<T, EPI_BIAS, true>(a, cfg, stream) : hipErrorInvalidValue;
+static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, int n_cu, hipStream_t stream, bool prepare) {
+    if (a.dbg) return epi == EPI_BIAS ? launch_ring_e<T, EPI_BIAS, true>(a, cfg, n_cu, stream, prepare) : hipErrorInvalidValue;
     switch (epi) {
-    case EPI_BIAS: return launch_ring_e<T, EPI_BIAS, false>(a, cfg, stream);
-    case EPI_BIAS_GELU: return launch_ring_e<T, EPI_BIAS_GELU, false>(a, cfg, stream);
-    case EPI_BIAS_RESID: return launch_ring_e<T, EPI_BIAS_RESID, false>(a, cfg, stream);
-    case EPI_BIAS_F32: return launch_ring_e<T, EPI_BIAS_F32, false>(a, cfg, stream);
-    case EPI_PATCH: return launch_ring_e<T, EPI_PATCH, false>(a, cfg, stream);
+    case EPI_BIAS: return launch_ring_e<T, EPI_BIAS, false>(a, cfg, n_cu, stream, prepare);
+    case EPI_BIAS_GELU: return launch_ring_e<T, EPI_BIAS_GELU, false>(a, cfg, n_cu, stream, prepare);
+    case EPI_BIAS_RESID: return launch_ring_e<T, EPI_BIAS_RESID, false>(a, cfg, n_cu, stream, prepare);
+    case EPI_BIAS_F32: return launch_ring_e<T, EPI_BIAS_F32, false>(a, cfg, n_cu, stream, prepare);
+    case EPI_PATCH: return launch_ring_e<T, EPI_PATCH, false>(a, cfg, n_cu, stream, prepare);
     default: return hipErrorInvalidValue;
     }
 }
@@ -504,10 +498,10 @@ bool gemm_ring_supports(const GemmArgs &a, int cfg) {
     return a.M % (c.nwm * c.wmt * 32) == 0 && a.N_pad % (c.nwn * c.wnt * 32) == 0 && a.K % (16 * c.ks) == 0 && a.K >= 32 * c.ks;
 }
 
-hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a0, int cfg, hipStream_t stream) {
+hipError_t launch_gemm_ring(const Tuning &t, int dtype, int epi, const GemmArgs &a0, int cfg, hipStream_t stream, bool prepare) {
+    if (prepare) return dtype == DT_F16 ? launch_ring_t<_Float16>(a0, epi, cfg, t.n_cu, stream, true) : launch_ring_t<__bf16>(a0, epi, cfg, t.n_cu, stream, true);
     if (!gemm_ring_supports(a0, cfg)) return hipErrorInvalidValue;
-    static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("VITX_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    const int dbg = t.gemm_dbg;
     GemmArgs a = a0; a.dbg = dbg;
     if (dbg & 32) {      // experiment mode: collect and print a per-block timeline (synchronous)
         RingCfg c; parse_cfg(cfg, c);
@@ -515,7 +509,7 @@ hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a0, int cfg, hip
         long long *buf = nullptr;
         if (hipHostMalloc((void **)&buf, (size_t)nwg * 32, 0) != hipSuccess) return hipErrorOutOfMemory;
         a.pos = (const float *)buf;
-        hipError_t e = dtype == DT_F16 ? launch_ring_t<_Float16>(a, epi, cfg, stream) : launch_ring_t<__bf16>(a, epi, cfg, stream);
+        hipError_t e = dtype == DT_F16 ? launch_ring_t<_Float16>(a, epi, cfg, t.n_cu, stream, false) : launch_ring_t<__bf16>(a, epi, cfg, t.n_cu, stream, false);
         (void)hipDeviceSynchronize();
         long long t0 = buf[0], t1 = 0; double sum = 0, sumc = 0;
         for (int b = 0; b < nwg; ++b) { t0 = std::min(t0, buf[b * 4]); t1 = std::max(t1, buf[b * 4 + 1]); sum += buf[b * 4 + 1] - buf[b * 4]; sumc += buf[b * 4 + 2]; }
@@ -523,7 +517,7 @@ hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a0, int cfg, hip
         (void)hipHostFree(buf);
         return e;
     }
-    return dtype == DT_F16 ? launch_ring_t<_Float16>(a, epi, cfg, stream) : launch_ring_t<__bf16>(a, epi, cfg, stream);
+    return dtype == DT_F16 ? launch_ring_t<_Float16>(a, epi, cfg, t.n_cu, stream, false) : launch_ring_t<__bf16>(a, epi, cfg, t.n_cu, stream, false);
 }
 
 }  // namespace vitx

@@ -29,7 +29,25 @@ struct GemmArgs {
     int dbg;      // ablation bits for kernel experiments (VITX_GEMM_DBG): 1 no DMA in loop, 2 no ds_read in loop, 4 no MFMA, 8 no epilogue
 };
 
-hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream);
+// Per-device launch parameters.  Everything a launcher used to keep in function-local statics (CU count, "dynamic LDS
+// attribute already set", getenv results) lives here: one immutable copy per device, built by tuning_for_device() under a
+// lock, so contexts on several GPUs (or host threads) of one process never share launch state.
+struct Tuning {
+    int device = 0;
+    int n_cu = 256;          // compute units of THIS device
+    int gemm_cfg = -1;       // VITX_GEMM_CFG: -1 auto, 0 = "v1" 128x128 kernel, 1 = "pp" forced, else a ring cfg (445, 945, 245, 122)
+    int gemm_pp = 1;         // VITX_GEMM_PP=0: wide tiles through the r01 ring/stream kernels instead of the ping-pong kernel
+    int gemm_stream = 1;     // VITX_GEMM_STREAM=0: one workgroup per tile (445) instead of the persistent 945 when the ring kernels run
+    int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
+    int gemm_split = 1;      // VITX_GEMM_NOSPLIT unsets (tail rows re-tiled 128x256)
+    int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
+    int attn_waves = 4;      // VITX_ATTN_WAVES
+};
+// Looks the device up (hipGetDevice when device < 0), reads the environment once per process, and on first use of a device
+// sets the dynamic-LDS attribute of every kernel instantiation on it.  Thread-safe.  Returns nullptr if HIP fails.
+const Tuning *tuning_for_device(int device);
+
+hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream);
 int gemm_tile_m();   // M granularity the GEMM needs (buffer row padding)
 int gemm_tile_n();
 
@@ -40,9 +58,18 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_i
 // y[r][:] (dtype) = LN(x[r*ldx ...]) * w + b   (vit.cpp:808-812)
 hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream);
 // fused per-(image,head) attention  (vit.cpp:826-866)
-hipError_t launch_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream);
+hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream);
+bool attention_supports(int N, int D, int H);     // instantiation table of the fused kernel
+bool layernorm_supports(int D);
 // class softmax with the reference's fp16 (or bf16) exp rounding (vit.cpp:931)
 hipError_t launch_softmax(int dtype, const float *logits, float *probs, int rows, int cols, int ld, hipStream_t stream);
 hipError_t launch_preprocess(const void *u8, float *out, int n, int nx, int ny, int S, int bicubic, hipStream_t stream);
+
+
+// internal: kernel families.  `prepare` = only set the dynamic-LDS attribute of the instantiation (device bring-up).
+hipError_t launch_gemm_ring(const Tuning &t, int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream, bool prepare = false);
+bool gemm_ring_supports(const GemmArgs &a, int cfg);
+hipError_t launch_gemm_pp(int dtype, int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags = 0, bool prepare = false);
+bool gemm_pp_supports(const GemmArgs &a);
 
 }  // namespace vitx

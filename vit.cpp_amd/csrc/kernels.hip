@@ -8,6 +8,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <memory>
+#include <mutex>
+#include <vector>
 
 #include "kernels.h"
 #include "device_common.h"
@@ -138,13 +141,12 @@ int gemm_tile_m() { return 256; }   // row padding of every activation buffer (r
 int gemm_tile_n() { return GBN; }
 
 template <typename T>
-static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream) {
-    const int grid = (a.M / GBM) * (a.N_pad / GBN);
+static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream, bool prepare) {
+    const int grid = prepare ? 1 : (a.M / GBM) * (a.N_pad / GBN);
     const dim3 blk(256);
 #define VITX_GEMM_CASE(E)                                                                                   \
     case E: {                                                                                               \
-        static bool attr_set = false;                                                                       \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES); attr_set = true; } \
+        if (prepare) return hipFuncSetAttribute((const void *)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES); \
         hipLaunchKernelGGL((gemm_nt_kernel<T, E>), dim3(grid), blk, G_LDS_BYTES, stream, a);                \
     } break;
     switch (epi) {
@@ -159,70 +161,56 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream) 
     return hipGetLastError();
 }
 
-bool gemm_ring_supports(const GemmArgs &a, int cfg);
-hipError_t launch_gemm_ring(int dtype, int epi, const GemmArgs &a, int cfg, hipStream_t stream);
+// Kernel selection (t.gemm_cfg overrides it for experiments).
+//   * >= 128 tiles of 256x256 and K % 128 == 0: the ping-pong persistent kernel (gemm_pp.hip);
+//   * otherwise 128x256 ring tiles, or the skinny 64x128 ring kernel when even those would leave most CUs idle
+//     (a handful of images: same K order per element, so results stay bit-identical across batch sizes);
+//   * anything the ring kernels cannot tile: the v1 128x128 kernel.
+static int wide_ring_cfg(const Tuning &t, const GemmArgs &a) { return (t.gemm_stream && gemm_ring_supports(a, 945)) ? 945 : 445; }
 
-// Kernel selection.  VITX_GEMM_CFG overrides it for experiments: "v1" (128x128 two-stage kernel) or
-// WMT*100+NWN*10+NS of the ring kernel ("445": 256x256 tile, 8 waves, 5-slot ring, one workgroup per tile; "945": the same as a persistent stream kernel; "245": 128x256).
-static int gemm_cfg_override() {
-    static int cfg = -2;
-    if (cfg == -2) {
-        const char *e = getenv("VITX_GEMM_CFG");
-        cfg = !e ? -1 : (!strcmp(e, "v1") ? 0 : atoi(e));
-    }
-    return cfg;
+static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
+    if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, t.n_cu, stream);
+    return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(t, a), stream);
 }
 
-// 256x256-tile kernel flavour: the persistent stream kernel (945) unless VITX_GEMM_STREAM=0 asks for one workgroup per tile (445)
-static int wide_cfg(const GemmArgs &a) {
-    static int stream_on = -1;
-    if (stream_on < 0) { const char *e = getenv("VITX_GEMM_STREAM"); stream_on = e ? atoi(e) : 1; }
-    return (stream_on && gemm_ring_supports(a, 945)) ? 945 : 445;
-}
-
-hipError_t launch_gemm(int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
+hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
-    int cfg = gemm_cfg_override();
+    int cfg = t.gemm_cfg;
+    if (cfg == 1) return launch_gemm_pp(dtype, epi, a, t.n_cu, stream);
+    if (cfg > 1) return gemm_ring_supports(a, cfg) ? launch_gemm_ring(t, dtype, epi, a, cfg, stream) : hipErrorInvalidValue;
     if (cfg < 0) {
-        // 256x256 tiles (8 waves, 5-slot ring) whenever the shape allows and there is at least a wave of tiles;
-        // 128x256 tiles for short M (e.g. the classifier head) -- measured in profiles/r01_gemm_configs.txt
         const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
-        cfg = (a.M % 256 == 0 && t256 >= 128) ? 445 : 245;
-        // a handful of images: 128x256 tiles would leave most CUs idle behind a serial K loop; 64x128 tiles (same K order per
-        // element, so bit-identical results) spread the same work over 8x the workgroups
-        static const bool skinny_on = getenv("VITX_GEMM_NOSKINNY") == nullptr;
-        if (cfg == 245 && skinny_on && (long)(a.M / 128) * (a.N_pad / 256) < 64 && gemm_ring_supports(a, 122)) cfg = 122;
-    }
-    if (cfg == 945 && !gemm_ring_supports(a, 945)) cfg = gemm_ring_supports(a, 445) ? 445 : 245;
-    // Tail split: one 256x256 tile per CU per round means e.g. 591 tiles (N = 768) cost 3 rounds for 2.31 rounds of
-    // work.  Rows that fill whole rounds keep 256x256 tiles; the remaining rows are re-tiled 128x256 (half-cost tiles)
-    // in a second launch, which turns a 0.3-round remainder into ~0.35 rounds instead of a full one.
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
-    if (cfg == 445 && gemm_cfg_override() < 0 && epi != EPI_PATCH && gemm_ring_supports(a, 445) && getenv("VITX_GEMM_NOSPLIT") == nullptr) {   // 50-iteration A/B: proj +4.5 %, fc2 +5 %, fc1 +-0
-        const int ntm = a.M / 256, ntn = a.N_pad / 256;
-        const long tiles = (long)ntm * ntn, rounds = tiles / n_cu, rem = tiles % n_cu;
-        if (rounds >= 1 && rem > 0 && rem <= n_cu * 6 / 10) {
-            const int m_main = (int)((rounds * n_cu) / ntn);                 // m-tiles that fit in whole rounds
-            const int rows_main = m_main * 256;
-            if (m_main >= 1 && rows_main < a.M) {
+        const bool wide = a.M % 256 == 0 && a.N_pad % 256 == 0 && t256 >= 128 && (gemm_pp_supports(a) || gemm_ring_supports(a, 445));
+        if (wide) {
+            // Tail split: one 256x256 tile per CU per round means e.g. 591 tiles (N = 768) cost 3 rounds for 2.31 rounds of
+            // work.  Rows that fill whole rounds keep 256x256 tiles; the remaining rows are re-tiled 128x256 (half-cost tiles)
+            // in a second launch, which turns a 0.3-round remainder into ~0.35 rounds instead of a full one.
+            const int ntm = a.M / 256, ntn = a.N_pad / 256;
+            const long tiles = (long)ntm * ntn, rounds = tiles / t.n_cu, rem = tiles % t.n_cu;
+            if (t.gemm_split && epi != EPI_PATCH && rounds >= 1 && rem > 0 && rem <= t.n_cu * 6 / 10) {
+                const int m_main = (int)((rounds * t.n_cu) / ntn);                 // m-tiles that fit in whole rounds
+                const int rows_main = m_main * 256;
                 GemmArgs head = a, tail = a;
                 head.M = rows_main; head.M_real = std::min(a.M_real, rows_main);
                 const size_t esz_out = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? 2 : 4;
                 tail.A = (const char *)a.A + (size_t)rows_main * a.lda * 2;
                 tail.out = (char *)a.out + (size_t)rows_main * a.ldo * esz_out;
                 tail.M = a.M - rows_main; tail.M_real = a.M_real - rows_main;
-                hipError_t e = launch_gemm_ring(dtype, epi, head, wide_cfg(head), stream);
-                if (e != hipSuccess) return e;
-                if (tail.M_real <= 0) return hipSuccess;
-                return launch_gemm_ring(dtype, epi, tail, 245, stream);
+                if (m_main >= 1 && rows_main < a.M && gemm_ring_supports(tail, 245)) {
+                    hipError_t e = launch_wide(t, dtype, epi, head, stream);
+                    if (e != hipSuccess) return e;
+                    if (tail.M_real <= 0) return hipSuccess;
+                    return launch_gemm_ring(t, dtype, epi, tail, 245, stream);
+                }
             }
+            return launch_wide(t, dtype, epi, a, stream);
         }
+        cfg = 245;
+        if (t.gemm_skinny && (long)(a.M / 128) * (a.N_pad / 256) < 64 && gemm_ring_supports(a, 122)) cfg = 122;
+        if (gemm_ring_supports(a, cfg)) return launch_gemm_ring(t, dtype, epi, a, cfg, stream);
     }
-    if (cfg == 445 && gemm_cfg_override() < 0) cfg = wide_cfg(a);
-    if (cfg > 0 && gemm_ring_supports(a, cfg)) return launch_gemm_ring(dtype, epi, a, cfg, stream);
     if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
-    return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream) : launch_gemm_t<__bf16>(epi, a, stream);
+    return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream, false) : launch_gemm_t<__bf16>(epi, a, stream, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -333,6 +321,9 @@ static hipError_t launch_layernorm_t(const float *x, long ldx, const float *w, c
     }
 #undef VITX_LN_CASE
     return hipGetLastError();
+}
+bool layernorm_supports(int D) {
+    switch (D) { case 64: case 128: case 192: case 256: case 384: case 512: case 768: case 1024: case 1280: case 1536: return true; default: return false; }
 }
 hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream) {
     return dtype == DT_F16 ? launch_layernorm_t<_Float16>(x, ldx, w, b, y, ldy, M, D, eps, stream) : launch_layernorm_t<__bf16>(x, ldx, w, b, y, ldy, M, D, eps, stream);
@@ -504,13 +495,12 @@ __global__ __launch_bounds__(NWAVES * 64, (NKT <= 9 && NWAVES <= 4) ? 2 : 1) voi
 template <typename T, int NKT, int NWAVES>
 static hipError_t launch_attention_inst(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     constexpr int lds = NKT * 32 * 128 + 64 * (NKT * 32 + 8) * 2;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)attention_kernel<T, NKT, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr_set = true; }
+    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_kernel<T, NKT, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
     hipLaunchKernelGGL((attention_kernel<T, NKT, NWAVES>), dim3(n_img * H), dim3(NWAVES * 64), lds, stream, (const T *)qkv, (T *)out, N, D, H);
     return hipGetLastError();
 }
 template <typename T>
-static hipError_t launch_attention_t(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+static hipError_t launch_attention_t(int attn_waves, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     const int nkt = (N + 31) / 32;
     switch (nkt) {
     case 1: return launch_attention_inst<T, 1, 1>(qkv, out, n_img, N, D, H, stream);
@@ -522,18 +512,74 @@ static hipError_t launch_attention_t(const void *qkv, void *out, int n_img, int 
     case 7: {                                                                             // 197 tokens (224/16)
         // 4 waves x 2 query tiles, two workgroups per CU (one stages K/V while the other computes): 109 us vs 124 us for
         // one 7-wave workgroup per CU on 256 x 12 heads (VITX_ATTN_WAVES=7 keeps the latter for A/B runs)
-        static int w = -1;
-        if (w < 0) { const char *e = getenv("VITX_ATTN_WAVES"); w = e ? atoi(e) : 4; }
-        return w == 7 ? launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream) : launch_attention_inst<T, 7, 4>(qkv, out, n_img, N, D, H, stream);
+        return attn_waves == 7 ? launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream) : launch_attention_inst<T, 7, 4>(qkv, out, n_img, N, D, H, stream);
     }
     case 9: return launch_attention_inst<T, 9, 4>(qkv, out, n_img, N, D, H, stream);      // 257 tokens (224/14)
     case 19: return launch_attention_inst<T, 19, 4>(qkv, out, n_img, N, D, H, stream);    // 577 tokens (384/16)
     default: return hipErrorInvalidValue;
     }
 }
-hipError_t launch_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
-    if (D != H * 64) return hipErrorInvalidValue;
-    return dtype == DT_F16 ? launch_attention_t<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(qkv, out, n_img, N, D, H, stream);
+static const int kAttnNkt[] = {1, 2, 3, 4, 5, 6, 7, 9, 19};      // instantiated key-tile counts (tokens = 32 * nkt, rounded up)
+bool attention_supports(int N, int D, int H) {
+    if (D != H * 64 || N <= 0) return false;
+    const int nkt = (N + 31) / 32;
+    for (int k : kAttnNkt) if (k == nkt) return true;
+    return false;
+}
+hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+    if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
+    return dtype == DT_F16 ? launch_attention_t<_Float16>(t.attn_waves, qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(t.attn_waves, qkv, out, n_img, N, D, H, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-device launch state (see Tuning in kernels.h).
+// ------------------------------------------------------------------------------------------------
+static hipError_t prepare_device_kernels(const Tuning &t) {
+    GemmArgs none{};
+    hipError_t e;
+    for (int dt = 0; dt < 2; ++dt) {
+        for (int epi = 0; epi <= EPI_PATCH; ++epi) {
+            for (int cfg : {945, 445, 245, 122}) if ((e = launch_gemm_ring(t, dt, epi, none, cfg, nullptr, true)) != hipSuccess) return e;
+            if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
+            if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
+        }
+        for (int nkt : kAttnNkt) {
+            for (int w : {4, 7}) {
+                if (w == 7 && nkt != 7) continue;
+                e = dt == DT_F16 ? launch_attention_t<_Float16>(w, nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr) : launch_attention_t<__bf16>(w, nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr);
+                if (e != hipSuccess) return e;
+            }
+        }
+    }
+    return hipSuccess;
+}
+
+const Tuning *tuning_for_device(int device) {
+    static std::mutex mu;
+    static std::vector<std::unique_ptr<Tuning>> table;      // one entry per device, never moved or freed
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if ((size_t)device < table.size() && table[device]) return table[device].get();
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    if (cur != device && hipSetDevice(device) != hipSuccess) return nullptr;
+    std::unique_ptr<Tuning> t(new Tuning());
+    t->device = device;
+    if (hipDeviceGetAttribute(&t->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || t->n_cu <= 0) t->n_cu = 256;
+    auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+    if (const char *e = getenv("VITX_GEMM_CFG")) t->gemm_cfg = !strcmp(e, "v1") ? 0 : (!strcmp(e, "pp") ? 1 : atoi(e));
+    t->gemm_pp = env_int("VITX_GEMM_PP", 1);
+    t->gemm_stream = env_int("VITX_GEMM_STREAM", 1);
+    t->gemm_skinny = getenv("VITX_GEMM_NOSKINNY") == nullptr;
+    t->gemm_split = getenv("VITX_GEMM_NOSPLIT") == nullptr;
+    t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
+    t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
+    const hipError_t e = prepare_device_kernels(*t);
+    if (cur != device) (void)hipSetDevice(cur);
+    if (e != hipSuccess) return nullptr;
+    if ((size_t)device >= table.size()) table.resize(device + 1);
+    table[device] = std::move(t);
+    return table[device].get();
 }
 
 // ------------------------------------------------------------------------------------------------
