@@ -65,8 +65,9 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
     CK(hipDeviceSynchronize());
     g.A = A; g.W = W; g.bias = bias; g.out = out; g.pos = nullptr; g.M = M; g.M_real = M; g.N = N; g.N_pad = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = 0;
     unsigned *tl = nullptr;
-    if (v.kind == 1 && (v.cfg & 96)) { CK(hipMalloc(&tl, 256 * 8 * 64 * 4)); CK(hipMemset(tl, 0, 256 * 8 * 64 * 4)); g.pos = (const float *)tl; }
+    if (v.kind == 1 && (v.cfg & (96 | 1024))) { CK(hipMalloc(&tl, 256 * 8 * 64 * 4)); CK(hipMemset(tl, 0, 256 * 8 * 64 * 4)); g.pos = (const float *)tl; }
     if (v.kind == 1 && (v.cfg & 28)) check = false;
+    const bool brief = v.kind == 1 && (v.cfg & 1024) && (v.cfg & 12);
     auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(*g_tune, dtype, epi, g, v.cfg, 0) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
 
     // ---- check first (on a fresh output buffer): 4096 sampled outputs incl. the corners of the first and last tile
@@ -98,7 +99,7 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
                 if (epi == EPI_BIAS_GELU) { want = gelu_ref(want); tol = 2.5 * ulp * (fabs(want) + 0.02) + 3e-3 * ulp * 128; }
                 if (epi == EPI_BIAS_RESID) want += (double)prev[s];
                 const double err = fabs((double)got[s] - want) / tol;
-                if (!(err <= 1.0)) ++bad;
+                if (!(err <= 1.0)) { if (bad < 16 && getenv("LAB_SHOWBAD")) printf("   bad: m %d (%d) n %d (%d) got %g want %g\n", sm[s], sm[s] % 256, sn[s], sn[s] % 256, got[s], want); ++bad; }
                 if (!(err <= worst)) worst = err;
             }
             if (bad) snprintf(verdict, sizeof verdict, "CHECK FAILED %d/%d worst %.1f tol", bad, S, worst);
@@ -135,6 +136,17 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
             for (int i = 1; i < ns; ++i) printf((v.cfg & 64) && i % 5 == 0 ? " %u |" : " %u", st[i] - st[i - 1]);
             printf("\n");
         }
+        if (v.cfg & 1024) {     // arrival stamps: per barrier, arrival of the first-row wave 0 and of the second-row wave 4 (which is one barrier behind)
+            const unsigned *w0 = &h[0], *w4 = &h[4 * 64];
+            printf("   barrier#: release(~max arrival) interval | w0 slack, w4 slack  (w4 stamp i belongs to barrier i+1)\n");
+            unsigned prev = 0;
+            for (int i = 1; i < (brief ? 16 : 31); ++i) {
+                const unsigned a0 = w0[i], a4 = w4[i - 1];       // both arrive at global barrier i
+                const unsigned rel = (int)(a0 - a4) > 0 ? a0 : a4;
+                printf("   b%02d %s: interval %4u  w0 slack %4d  w4 slack %4d\n", i, (i & 1) ? "w0:B2/w4:B1" : "w0:B1/w4:B2", prev ? rel - prev : 0, (int)(rel - a0), (int)(rel - a4));
+                prev = rel;
+            }
+        }
         const unsigned *a0 = &h[0], *a4 = &h[4 * 64];
         printf("   wave4 - wave0 stamp offsets:"); for (int i = 0; i < 32; ++i) printf(" %d", (int)(a4[i] - a0[i])); printf("\n");
         CK(hipFree(tl));
@@ -158,7 +170,7 @@ int main(int argc, char **argv) {
         {"qkvL", 73984, 3072, 1024}, {"fc2L", 73984, 1024, 4096},
     };
     const Variant variants[] = {{"ring945", 0, 945}, {"pp", 1, 0}, {"pp_noprio", 1, 1}, {"pp_lock", 1, 2}, {"pp_nodma", 1, 4}, {"pp_noread", 1, 8}, {"pp_mfmaonly", 1, 12},
-                                {"pp_nomfma", 1, 16}, {"pp_readonly", 1, 20}, {"pp_dmaonly", 1, 24}, {"pp_stamp", 1, 32}, {"pp_nodma_stamp", 1, 36}, {"pp_noread_stamp", 1, 40}, {"pp_mfmaonly_stamp", 1, 44}, {"pp_dmaonly_stamp", 1, 56}, {"pp_fine", 1, 64}, {"pp_stagefirst", 1, 128}, {"pp_glds", 1, 256}, {"pp_drain", 1, 512}};
+                                {"pp_nomfma", 1, 16}, {"pp_readonly", 1, 20}, {"pp_dmaonly", 1, 24}, {"pp_stamp", 1, 32}, {"pp_nodma_stamp", 1, 36}, {"pp_noread_stamp", 1, 40}, {"pp_mfmaonly_stamp", 1, 44}, {"pp_dmaonly_stamp", 1, 56}, {"pp_fine", 1, 64}, {"pp_stagefirst", 1, 128}, {"pp_glds", 1, 256}, {"pp_drain", 1, 512}, {"pp_arrive", 1, 1024}, {"pp_arrive_nodma", 1, 1028}, {"pp_arrive_noread", 1, 1032}, {"pp_arrive_mfmaonly", 1, 1036}};
     for (const Shape &sh : shapes)
         for (const Variant &v : variants) {
             int epis[4] = {EPI_BIAS, -1, -1, -1};

@@ -35,7 +35,8 @@ namespace pp {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 16384;             // one half-tile image: 128 rows x 128 B
 constexpr int BUF = 4 * HALF;           // [A0 | A1 | B0 | B1]
-constexpr int LDS = 2 * BUF;            // 128 KiB
+constexpr int LDS = 2 * BUF;            // 128 KiB operand ring
+constexpr int LDS_ALL = LDS + 8 * 4096; // + one 4 KiB epilogue patch per wave = all 160 KiB
 constexpr int GROUP_M = 8;
 constexpr int STAGE_OPS = 2;            // LDS-DMA instructions per thread per half-tile
 constexpr int LEAD = 4;                 // stages allowed in flight past a phase's wait
@@ -93,73 +94,98 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &g, f32x16 (&acc)[4][
     }
 }
 
-// ---- full-tile epilogue with an EXACT number of vector-memory instructions (pp_epi_stores): every store is one
-// buffer_store_dwordx4 issued unconditionally, so the K loop of the next tile can skip over them with a counted vmcnt
-// instead of draining them (the stores of a 256x256 tile take ~8 us to retire when every CU stores at once).
-// 16-bit outputs: lanes l and l+32 hold columns 4hh..4hh+3 of each 8-column group; one v_permlane32_swap per dword
-// turns two groups into 8 contiguous columns per lane -> 16-byte stores.
+// ---- full-tile epilogue: EXACT number of vector-memory instructions (pp_epi_stores) and whole-row stores.
+//   * every store is one buffer_store_dwordx4 issued unconditionally, so the K loop of the next tile can skip over them
+//     with a counted vmcnt instead of draining them;
+//   * the accumulators hold one ROW per lane (a store straight from them touches 64 different 128-byte lines per
+//     instruction and the texture-address path serialises on lines: ~9k cycles per tile, r02 lab), so each 32-row block
+//     goes through a wave-private 4 KiB LDS patch (the 32 KiB the operand ring leaves free): written in the MFMA layout,
+//     read back with 8 lanes per 128-byte row, stored as whole lines (8 lines per instruction).
+//     Patch rows are 128 B; 16-byte slots are XOR-ed with (row & 7): conflict-free reads, <= 2-way writes.
+// A wave's own LDS write -> read (and read -> overwrite) through the patch needs an explicit lgkmcnt(0): with a bank-conflicted
+// ds_write_b64 the following ds_read_b128 returned the OLD bytes for the lanes of the write's second pass (r02: 1 % of the
+// GELU outputs wrong until this wait went in) -- LDS operations of one wave are not guaranteed to execute in issue order.
+__device__ __forceinline__ void pp_lds_fence() {
+    __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0);      // lgkmcnt(0), vmcnt/expcnt untouched
+}
 template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 template <typename T, int EPI>
-__device__ __forceinline__ void pp_epilogue_full(const GemmArgs &g, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t ro, int voff, int soff, int soff_step /* 32 rows */, int ncol, int hh) {
+__device__ __forceinline__ void pp_epilogue_full(const GemmArgs &g, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t ro, char *patch /* wave-private 4 KiB */,
+                                                  int voff /* this lane's byte offset in row layout */, int soff /* tile origin */, int soff8 /* 8 rows */, int ncol, int lane) {
     typedef const __attribute__((address_space(4))) float *cptr;     // constant address space: wave-uniform -> s_load (no vmcnt traffic)
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wr_row = l31 * 128, x16 = (l31 & 7) * 16;                                     // MFMA layout: this lane's patch row
+    const int rd_off = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);         // row layout: row (lane>>3) + 8t, 16-byte piece lane&7
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         typedef typename Pair<T>::v2 v2;
+        // bias of this lane's 32 columns (8 groups of 4), selected once per tile
+        float bq[8][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < 8; ++q) {
+            cptr cb = (cptr)(g.bias + ncol + q * 8);
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                cptr cb = (cptr)(g.bias + ncol + j * 32 + pr * 16);
-                float bA[4], bB[4];
+            for (int e = 0; e < 4; ++e) { const float lo = cb[e], hi = cb[4 + e]; bq[q][e] = hh ? hi : lo; }
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float a0 = cb[e], a1 = cb[4 + e], b0 = cb[8 + e], b1 = cb[12 + e]; bA[e] = hh ? a1 : a0; bB[e] = hh ? b1 : b0; }
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float vA[4], vB[4];
+            for (int q = 0; q < 8; ++q) {          // q = j*4 + rg: columns q*8 + 4hh .. +3 -> 8 bytes of slot q
+                const int j = q >> 2, rg = q & 3;
+                float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { vA[e] = acc[i][j][pr * 8 + e] + bA[e]; vB[e] = acc[i][j][pr * 8 + 4 + e] + bB[e]; }
-                    v2 pA0 = round_pair<T>(vA[0], vA[1]), pA1 = round_pair<T>(vA[2], vA[3]), pB0 = round_pair<T>(vB[0], vB[1]), pB1 = round_pair<T>(vB[2], vB[3]);
-                    if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
-                        const f32x2 yA0 = gelu_tanh2(f32x2{(float)pA0[0], (float)pA0[1]}), yA1 = gelu_tanh2(f32x2{(float)pA1[0], (float)pA1[1]});
-                        const f32x2 yB0 = gelu_tanh2(f32x2{(float)pB0[0], (float)pB0[1]}), yB1 = gelu_tanh2(f32x2{(float)pB1[0], (float)pB1[1]});
-                        pA0 = round_pair<T>(yA0[0], yA0[1]); pA1 = round_pair<T>(yA1[0], yA1[1]); pB0 = round_pair<T>(yB0[0], yB0[1]); pB1 = round_pair<T>(yB1[0], yB1[1]);
-                    }
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pA0), __builtin_bit_cast(unsigned, pB0), false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pA1), __builtin_bit_cast(unsigned, pB1), false, false);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, ro, voff + (j * 64 + pr * 32), soff + i * soff_step, 0);
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + bq[q][e];
+                v2 p0 = round_pair<T>(v[0], v[1]), p1 = round_pair<T>(v[2], v[3]);
+                if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
+                    const f32x2 y0 = gelu_tanh2(f32x2{(float)p0[0], (float)p0[1]}), y1 = gelu_tanh2(f32x2{(float)p1[0], (float)p1[1]});
+                    p0 = round_pair<T>(y0[0], y0[1]); p1 = round_pair<T>(y1[0], y1[1]);
                 }
+                *(u32x2 *)(patch + wr_row + ((q * 16) ^ x16) + hh * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
             }
-    } else {       // f32 outputs: 4 consecutive columns per lane and group -> 16-byte stores (and loads, for the residual)
+            pp_lds_fence();
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            u32x4 res[2][2][4];
-            if constexpr (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) res[ii][j][rg] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + (j * 128 + rg * 32), soff + (half * 2 + ii) * soff_step, 0);
+            for (int t = 0; t < 4; ++t) {
+                const u32x4 d = *(const u32x4 *)(patch + t * 1024 + rd_off);
+                __builtin_amdgcn_raw_buffer_store_b128(d, ro, voff, soff + (i * 4 + t) * soff8, 0);
             }
+            pp_lds_fence();
+        }
+    } else {       // f32 outputs: one 32 x 32 accumulator block (4 KiB) per pass
+        float bq[8][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < 8; ++q) {
+            cptr cb = (cptr)(g.bias + ncol + q * 8);
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    cptr cb = (cptr)(g.bias + ncol + j * 32 + rg * 8);
-                    float bv[4];
+            for (int e = 0; e < 4; ++e) { const float lo = cb[e], hi = cb[4 + e]; bq[q][e] = hh ? hi : lo; }
+        }
+        u32x4 res[2][4];                            // residual rows of the current and the next pass (loads run one pass ahead)
+        auto load_res = [&](int c, u32x4 (&dst)[4]) {
+            const int i = c >> 1, j = c & 1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float lo = cb[e], hi = cb[4 + e]; bv[e] = hh ? hi : lo; }
+            for (int t = 0; t < 4; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+        };
+        if constexpr (EPI == EPI_BIAS_RESID) load_res(0, res[0]);
 #pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const int i = half * 2 + ii;
-                        f32x4 v;
+        for (int c = 0; c < 8; ++c) {
+            const int i = c >> 1, j = c & 1;
+            if constexpr (EPI == EPI_BIAS_RESID) { if (c + 1 < 8) load_res(c + 1, res[(c + 1) & 1]); }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + bv[e];
-                        if constexpr (EPI == EPI_BIAS_RESID) v = v + __builtin_bit_cast(f32x4, res[ii][j][rg]);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, voff + (j * 128 + rg * 32), soff + i * soff_step, 0);
-                    }
-                }
+            for (int rg = 0; rg < 4; ++rg) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rg * 4 + e] + bq[j * 4 + rg][e];
+                *(f32x4 *)(patch + wr_row + (((rg * 2 + hh) * 16) ^ x16)) = v;
+            }
+            pp_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 d = *(const f32x4 *)(patch + t * 1024 + rd_off);
+                if constexpr (EPI == EPI_BIAS_RESID) d = d + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+            }
+            pp_lds_fence();
         }
     }
 }
@@ -285,6 +311,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
             }
         }
     };
+    unsigned long long t_arr = 0;                   // FLAGS 1024: arrival times at the barriers (sampled before, consumed after: ~no perturbation)
+    auto arrive = [&]() { if constexpr ((FLAGS & 1024) != 0) { if (n_stamp >= 0 && n_stamp < 64) t_arr = __builtin_readcyclecounter(); } };
+    auto arrived = [&]() {
+        if constexpr ((FLAGS & 1024) != 0) { if (n_stamp >= 0 && n_stamp < 64) { stamps = lane == n_stamp ? (unsigned)t_arr : stamps; ++n_stamp; } }
+    };
     auto fine_stamp = [&]() {                       // FLAGS 64: five stamps per phase (after B2, after the stage issue, after the vmcnt wait, after B1 + reads landed, after the MFMAs)
         if constexpr ((FLAGS & 64) != 0) {
             if (n_stamp >= 0 && n_stamp < 64) {
@@ -308,17 +339,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
             if (!(FLAGS & 4)) { STAGE; }                                                   \
             if (RLX) pp_wait_vmcnt<VMCNT + pp_epi_stores<EPI>()>(); else pp_wait_vmcnt<VMCNT>();   \
         }                                                                                  \
+        arrive();                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         pp_barrier();                                                                      \
-        stamp(); fine_stamp();                                                             \
+        stamp(); fine_stamp(); arrived();                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(1);                                   \
         if (!(FLAGS & 16)) mma(HA, HB);                                                    \
         if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(0);                                   \
         __builtin_amdgcn_sched_barrier(0);                                                 \
-        fine_stamp();                                                                      \
+        fine_stamp(); arrive();                                                            \
         pp_barrier();                                                                      \
-        stamp(); fine_stamp();                                                             \
+        stamp(); fine_stamp(); arrived();                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }
     // `relaxed`: the first K-tile after a full-tile epilogue -- its stores are younger than the stages these four waits
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
         for (int kt = 0; kt < nkt; kt += 2) {
-            if constexpr ((FLAGS & (32 | 64)) != 0) { if (round == 0 && kt == 4) n_stamp = 0; }
+            if constexpr ((FLAGS & (32 | 64 | 1024)) != 0) { if (round == 0 && kt == 4) n_stamp = 0; }
             ktile(I0{}); ktile(I1{});
         }
         if constexpr ((FLAGS & 8) != 0) {           // fragments never read: keep the MFMA operands "defined" for the compiler
@@ -362,10 +394,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
         if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
             constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
-            const int voff = ((wr * 128 + l31) * g.ldo + wc * 64 + hh * (esz == 2 ? 8 : 4)) * esz;
+            // row layout of the stores: lane -> row (lane>>3) + 8t of a 32-row block, 16-byte piece lane&7 of the wave's 128-byte row segment
+            const int voff = ((wr * 128 + (lane >> 3)) * g.ldo + wc * 64) * esz + (lane & 7) * 16;
             // readfirstlane: the tile origin comes out of an integer division done on the VALU; without it hipcc wraps every
             // buffer op in a waterfall loop over the (uniform) SGPR offset
-            pp_epilogue_full<T, EPI>(g, acc, rsrcO, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 32 * g.ldo * esz, __builtin_amdgcn_readfirstlane(n0 + wc * 64), hh);
+            pp_epilogue_full<T, EPI>(g, acc, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz,
+                                     __builtin_amdgcn_readfirstlane(n0 + wc * 64), lane);
             relaxed = true;
         } else {
             const int row0 = m0 + wr * 128 + l31, ncol = n0 + wc * 64;
@@ -375,7 +409,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     }
     if (!(FLAGS & 2) && wr == 0) pp_barrier();
     pp_wait_vmcnt<0>();                             // the trailing (unused) stages must land before the LDS allocation is released
-    if constexpr ((FLAGS & (32 | 64)) != 0) ((unsigned *)g.pos)[((size_t)bid * 8 + wave) * 64 + lane] = stamps;
+    if constexpr ((FLAGS & (32 | 64 | 1024)) != 0) ((unsigned *)g.pos)[((size_t)bid * 8 + wave) * 64 + lane] = stamps;
 #undef PP_PHASE
 }
 
@@ -389,14 +423,14 @@ bool gemm_pp_supports(const GemmArgs &a) {
 template <typename T, int EPI, int FLAGS>
 static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream, bool prepare) {
     if (prepare || FLAGS) {     // once per device (tuning_for_device); the experiment builds set it on every launch
-        hipError_t e = hipFuncSetAttribute((const void *)gemm_pp_kernel<T, EPI, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS);
+        hipError_t e = hipFuncSetAttribute((const void *)gemm_pp_kernel<T, EPI, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_ALL);
         if (prepare) return e;
     }
     const int ntiles = (a.M / pp::BM) * (a.N_pad / pp::BN);
     int cap = n_cu & ~7;                             // the tile walk keeps a workgroup on one XCD: grid is a multiple of 8
     if (cap <= 0) cap = 256;
     const int grid = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI, FLAGS>), dim3(grid), dim3(512), pp::LDS, stream, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI, FLAGS>), dim3(grid), dim3(512), pp::LDS_ALL, stream, a);
     return hipGetLastError();
 }
 template <typename T>
@@ -421,6 +455,10 @@ static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t 
         case 128: return launch_pp_inst<T, EPI_BIAS, 128>(a, n_cu, stream, prepare);
         case 256: return launch_pp_inst<T, EPI_BIAS, 256>(a, n_cu, stream, prepare);
         case 512: return launch_pp_inst<T, EPI_BIAS, 512>(a, n_cu, stream, prepare);
+        case 1024: return launch_pp_inst<T, EPI_BIAS, 1024>(a, n_cu, stream, prepare);
+        case 1028: return launch_pp_inst<T, EPI_BIAS, 1028>(a, n_cu, stream, prepare);
+        case 1032: return launch_pp_inst<T, EPI_BIAS, 1032>(a, n_cu, stream, prepare);
+        case 1036: return launch_pp_inst<T, EPI_BIAS, 1036>(a, n_cu, stream, prepare);
         default: return hipErrorInvalidValue;
         }
     }

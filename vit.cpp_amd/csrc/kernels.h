@@ -39,7 +39,7 @@ struct Tuning {
     int gemm_pp = 1;         // VITX_GEMM_PP=0: wide tiles through the r01 ring/stream kernels instead of the ping-pong kernel
     int gemm_stream = 1;     // VITX_GEMM_STREAM=0: one workgroup per tile (445) instead of the persistent 945 when the ring kernels run
     int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
-    int gemm_split = 1;      // VITX_GEMM_NOSPLIT unsets (tail rows re-tiled 128x256)
+    int gemm_split = 0;      // VITX_GEMM_SPLIT=1: tail rows of a partial round re-tiled 128x256 in a second launch (r01 default; off since the persistent kernel)
     int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
     int attn_waves = 4;      // VITX_ATTN_WAVES
 };

@@ -571,7 +571,7 @@ const Tuning *tuning_for_device(int device) {
     t->gemm_pp = env_int("VITX_GEMM_PP", 1);
     t->gemm_stream = env_int("VITX_GEMM_STREAM", 1);
     t->gemm_skinny = getenv("VITX_GEMM_NOSKINNY") == nullptr;
-    t->gemm_split = getenv("VITX_GEMM_NOSPLIT") == nullptr;
+    t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);      // r02: with the persistent ping-pong kernel the two-launch tail split costs 5 % of the step (profiles/r02_forward_sweeps.txt)
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
     const hipError_t e = prepare_device_kernels(*t);
