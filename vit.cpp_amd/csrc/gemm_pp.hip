@@ -102,35 +102,38 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &g, f32x16 (&acc)[4][
 //     goes through a wave-private 4 KiB LDS patch (the 32 KiB the operand ring leaves free): written in the MFMA layout,
 //     read back with 8 lanes per 128-byte row, stored as whole lines (8 lines per instruction).
 //     Patch rows are 128 B; 16-byte slots are XOR-ed with (row & 7): conflict-free reads, <= 2-way writes.
-// A wave's own LDS write -> read (and read -> overwrite) through the patch needs an explicit lgkmcnt(0): with a bank-conflicted
-// ds_write_b64 the following ds_read_b128 returned the OLD bytes for the lanes of the write's second pass (r02: 1 % of the
-// GELU outputs wrong until this wait went in) -- LDS operations of one wave are not guaranteed to execute in issue order.
-__device__ __forceinline__ void pp_lds_fence() {
-    __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0);      // lgkmcnt(0), vmcnt/expcnt untouched
-}
-template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <typename T, int EPI>
-__device__ __forceinline__ void pp_epilogue_full(const GemmArgs &g, f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t ro, char *patch /* wave-private 4 KiB */,
-                                                  int voff /* this lane's byte offset in row layout */, int soff /* tile origin */, int soff8 /* 8 rows */, int ncol, int lane) {
-    typedef const __attribute__((address_space(4))) float *cptr;     // constant address space: wave-uniform -> s_load (no vmcnt traffic)
+// The patch is written and read back by the same wave through different vector types: a compiler-level barrier keeps those
+// accesses in program order (the LDS itself executes one wave's operations in issue order -- verified in r02 with and without an
+// lgkmcnt(0) between the writes and the reads).
+__device__ __forceinline__ void pp_lds_fence() { asm volatile("" ::: "memory"); }
+
+// 16-byte buffer store followed by the wait states hipcc does not insert: with an SGPR soffset LLVM's hazard recognizer assumes
+// "store of more than 64 bits -> VALU overwrite of its data registers" cannot happen, but on gfx950 the very next VALU write DID
+// corrupt the stored dwords (r02: 0.7 % of the f32-epilogue outputs, 1 % of the GELU outputs, always the same lanes).
+__device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(d, ro, voff, soff, 0);
+    __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+}
+template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
+
+template <typename T, int EPI, bool NOSTORE = false>
+__device__ __forceinline__ void pp_epilogue_full(f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t ro, char *patch /* wave-private 4 KiB; its first 256 B hold the bias of the wave's 64 columns */,
+                                                  int voff /* this lane's byte offset in row layout */, int soff /* tile origin */, int soff8 /* 8 rows */, int lane) {
     const int l31 = lane & 31, hh = lane >> 5;
     const int wr_row = l31 * 128, x16 = (l31 & 7) * 16;                                     // MFMA layout: this lane's patch row
     const int rd_off = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);         // row layout: row (lane>>3) + 8t, 16-byte piece lane&7
+    // bias of this lane's 32 columns (8 groups q of 4: columns q*8 + 4hh ..), staged into the patch by LDS-DMA during the K loop
+    f32x4 bq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bq[q] = *(const f32x4 *)(patch + q * 32 + hh * 16);
+    pp_lds_fence();
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         typedef typename Pair<T>::v2 v2;
-        // bias of this lane's 32 columns (8 groups of 4), selected once per tile
-        float bq[8][4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            cptr cb = (cptr)(g.bias + ncol + q * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float lo = cb[e], hi = cb[4 + e]; bq[q][e] = hh ? hi : lo; }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        // one 32-row block: bias, (GELU,) pack -> 16 dwords per lane; the NEXT block is computed while this one's LDS writes land
+        auto compute = [&](int i, u32x2 (&w)[8]) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {          // q = j*4 + rg: columns q*8 + 4hh .. +3 -> 8 bytes of slot q
                 const int j = q >> 2, rg = q & 3;
@@ -142,24 +145,28 @@ __device__ __forceinline__ void pp_epilogue_full(const GemmArgs &g, f32x16 (&acc
                     const f32x2 y0 = gelu_tanh2(f32x2{(float)p0[0], (float)p0[1]}), y1 = gelu_tanh2(f32x2{(float)p1[0], (float)p1[1]});
                     p0 = round_pair<T>(y0[0], y0[1]); p1 = round_pair<T>(y1[0], y1[1]);
                 }
-                *(u32x2 *)(patch + wr_row + ((q * 16) ^ x16) + hh * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+                w[q] = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
             }
+        };
+        u32x2 w[2][8];
+        compute(0, w[0]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(u32x2 *)(patch + wr_row + ((q * 16) ^ x16) + hh * 8) = w[i & 1][q];
+            if (i + 1 < 4) compute(i + 1, w[(i + 1) & 1]);
+            pp_lds_fence();
+            u32x4 d[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = *(const u32x4 *)(patch + t * 1024 + rd_off);
             pp_lds_fence();
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const u32x4 d = *(const u32x4 *)(patch + t * 1024 + rd_off);
-                __builtin_amdgcn_raw_buffer_store_b128(d, ro, voff, soff + (i * 4 + t) * soff8, 0);
+                if constexpr (NOSTORE) asm volatile("" :: "v"(d[t])); else
+                pp_store_b128(d[t], ro, voff, soff + (i * 4 + t) * soff8);
             }
-            pp_lds_fence();
         }
     } else {       // f32 outputs: one 32 x 32 accumulator block (4 KiB) per pass
-        float bq[8][4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            cptr cb = (cptr)(g.bias + ncol + q * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float lo = cb[e], hi = cb[4 + e]; bq[q][e] = hh ? hi : lo; }
-        }
         u32x4 res[2][4];                            // residual rows of the current and the next pass (loads run one pass ahead)
         auto load_res = [&](int c, u32x4 (&dst)[4]) {
             const int i = c >> 1, j = c & 1;
@@ -179,19 +186,21 @@ __device__ __forceinline__ void pp_epilogue_full(const GemmArgs &g, f32x16 (&acc
                 *(f32x4 *)(patch + wr_row + (((rg * 2 + hh) * 16) ^ x16)) = v;
             }
             pp_lds_fence();
+            f32x4 d[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = *(const f32x4 *)(patch + t * 1024 + rd_off);
+            pp_lds_fence();
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                f32x4 d = *(const f32x4 *)(patch + t * 1024 + rd_off);
-                if constexpr (EPI == EPI_BIAS_RESID) d = d + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+                if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
+                pp_store_b128(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
             }
-            pp_lds_fence();
         }
     }
 }
 
 // FLAGS (experiments, tools/gemm_lab): 1 = no s_setprio around the MFMAs, 2 = both wave rows in lock-step (no ping-pong),
-// 512 = epilogue stores drained (no counted skip), 4 = no LDS-DMA in the loop, 8 = no fragment reads, 16 = no MFMAs, 32 = s_memtime stamp after every barrier of K-tiles 4..7 of
+// 2048 = no epilogue at all, 512 = epilogue stores drained (no counted skip), 4 = no LDS-DMA in the loop, 8 = no fragment reads, 16 = no MFMAs, 32 = s_memtime stamp after every barrier of K-tiles 4..7 of
 // the first tile (written to g.pos as [block][wave][64] u32)
 template <typename T, int EPI, int FLAGS>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
@@ -295,12 +304,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fb[h][ks] = *(const v8 *)(smem + buf * BUF + h * HALF + rdB[ks]);
     };
-    auto mma = [&](int ha, int hb) {
+    // MFMAs [first, last) of a quadrant's 8 (k-step major, so consecutive MFMAs alternate between its two accumulators)
+    auto mma = [&](int ha, int hb, int first, int last) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) acc[2 * ha + ii][hb] = Elem<T>::mfma(fb[hb][ks], fa[ii][ks], acc[2 * ha + ii][hb]);
+        for (int n = 0; n < 8; ++n) {
+            const int ks = n >> 1, ii = n & 1;
+            if (n >= first && n < last) acc[2 * ha + ii][hb] = Elem<T>::mfma(fb[hb][ks], fa[ii][ks], acc[2 * ha + ii][hb]);
+        }
     };
+
     unsigned stamps = 0; int n_stamp = -1;          // timeline experiment: lane i of `stamps` = i-th stamp
     auto stamp = [&]() {
         if constexpr ((FLAGS & 32) != 0) {
@@ -326,18 +338,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         }
     };
     // one phase = [reads, stage] | counted wait | barrier | 8 MFMAs | barrier
-#define PP_PHASE(READS, STAGE, VMCNT, HA, HB, RLX)                                              \
+#define PP_PHASE(READS, STAGE, VMCNT, HA, HB, FIRST, FIRST_STMT)                                              \
     {                                                                                      \
         if constexpr ((FLAGS & (64 | 128)) != 0) {                                         \
+            if (FIRST) { FIRST_STMT; }                                                     \
             if (!(FLAGS & 4)) { STAGE; }                                                   \
             fine_stamp();                                                                  \
-            pp_wait_vmcnt<VMCNT>();                                                        \
+            if (FIRST) { if (relaxed) pp_wait_vmcnt<VMCNT + 1 + pp_epi_stores<EPI>()>(); else pp_wait_vmcnt<VMCNT + 1>(); }   \
+            else pp_wait_vmcnt<VMCNT>();                                                   \
             fine_stamp();                                                                  \
             if (!(FLAGS & 8)) { READS; }                                                   \
         } else {                                                                           \
             if (!(FLAGS & 8)) { READS; }                                                   \
+            if (FIRST) { FIRST_STMT; }                                                     \
             if (!(FLAGS & 4)) { STAGE; }                                                   \
-            if (RLX) pp_wait_vmcnt<VMCNT + pp_epi_stores<EPI>()>(); else pp_wait_vmcnt<VMCNT>();   \
+            if (FIRST) { if (relaxed) pp_wait_vmcnt<VMCNT + 1 + pp_epi_stores<EPI>()>(); else pp_wait_vmcnt<VMCNT + 1>(); }   \
+            else pp_wait_vmcnt<VMCNT>();                                                   \
         }                                                                                  \
         arrive();                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         stamp(); fine_stamp(); arrived();                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(1);                                   \
-        if (!(FLAGS & 16)) mma(HA, HB);                                                    \
+        if (!(FLAGS & 16)) mma(HA, HB, 0, 8);                                              \
         if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(0);                                   \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         fine_stamp(); arrive();                                                            \
@@ -353,18 +369,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         stamp(); fine_stamp(); arrived();                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }
-    // `relaxed`: the first K-tile after a full-tile epilogue -- its stores are younger than the stages these four waits
-    // retire, so the count skips over exactly pp_epi_stores() of them instead of draining them.
+    // The first K-tile of a tile (`first`) also (a) zeroes each accumulator quadrant in the load part of the phase that first uses
+    // it (the wave is waiting for its partner there anyway), (b) DMA-loads the bias of the wave's 64 columns into its epilogue
+    // patch (one more vector-memory op, issued BEFORE the phase's stage so only this K-tile's four waits count it), and
+    // (c) if a full-tile epilogue ran just before (`relaxed`), skips over exactly pp_epi_stores() stores in those waits: they are
+    // younger than the stages being retired, and draining them costs microseconds when every CU stores at once.
     bool relaxed = false;
-    auto ktile = [&](auto bc) {
+    int bias_so = 0;                                 // byte offset of the consumer tile's bias columns
+    __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, (int)0xffffffffu, 0x00020000);
+    auto zero_quadrant = [&](int ha, int hb) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[2 * ha + ii][hb][r] = 0.0f;
+    };
+    auto stage_bias = [&]() { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, LPTR(smem + LDS + wave * 4096), 4, lane * 4, bias_so, 0, 0); };
+    auto ktile = [&](auto bc, bool first) {
         constexpr int B = decltype(bc)::value;       // buffer of the K-tile being consumed
         constexpr int O = (B ^ 1) * BUF, S = B * BUF, W8 = LEAD * STAGE_OPS;
-        const bool rlx = B == 0 && relaxed;
-        PP_PHASE((read_a(B, 0), read_b(B, 0)), stage_w(1, O + 3 * HALF), W8, 0, 0, rlx)                    // C00 ; B1 of the next K-tile
-        PP_PHASE(read_b(B, 1), (stage_a(1, O + 1 * HALF), advance()), W8, 0, 1, rlx)                        // C01 ; A1 of the next K-tile
-        PP_PHASE(read_a(B, 1), stage_a(0, S + 0 * HALF), W8, 1, 1, rlx)                                     // C11 ; A0 two K-tiles ahead
-        PP_PHASE((void)0, stage_w(0, S + 2 * HALF), W8, 1, 0, rlx)                                          // C10 ; B0 two K-tiles ahead
-        if (B == 0) relaxed = false;
+        const bool f = B == 0 && first;
+        PP_PHASE((read_a(B, 0), read_b(B, 0)), stage_w(1, O + 3 * HALF), W8, 0, 0, f, (zero_quadrant(0, 0), stage_bias()))   // C00 ; B1 of the next K-tile
+        PP_PHASE(read_b(B, 1), (stage_a(1, O + 1 * HALF), advance()), W8, 0, 1, f, zero_quadrant(0, 1))                        // C01 ; A1 of the next K-tile
+        PP_PHASE(read_a(B, 1), stage_a(0, S + 0 * HALF), W8, 1, 1, f, zero_quadrant(1, 1))                                     // C11 ; A0 two K-tiles ahead
+        PP_PHASE((void)0, stage_w(0, S + 2 * HALF), W8, 1, 0, f, zero_quadrant(1, 0))                                          // C10 ; B0 two K-tiles ahead
+        if (f) relaxed = false;
     };
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
 
@@ -377,29 +405,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 
     for (int round = 0; round < my_tiles; ++round) {
         int m0, n0; tile_origin(round, m0, n0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        bias_so = __builtin_amdgcn_readfirstlane((n0 + wc * 64) * 4);
         for (int kt = 0; kt < nkt; kt += 2) {
             if constexpr ((FLAGS & (32 | 64 | 1024)) != 0) { if (round == 0 && kt == 4) n_stamp = 0; }
-            ktile(I0{}); ktile(I1{});
+            ktile(I0{}, kt == 0); ktile(I1{}, false);
         }
         if constexpr ((FLAGS & 8) != 0) {           // fragments never read: keep the MFMA operands "defined" for the compiler
             if (round == 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(fa[ii][ks])); asm volatile("" : "+v"(fb[ii][ks])); } }
         }
         if constexpr ((FLAGS & 16) != 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" :: "v"(fa[ii][ks]), "v"(fb[ii][ks])); } }
         const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
-        if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
+        if constexpr ((FLAGS & 2048) != 0) {
+            asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
+        } else if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
             constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
             // row layout of the stores: lane -> row (lane>>3) + 8t of a 32-row block, 16-byte piece lane&7 of the wave's 128-byte row segment
             const int voff = ((wr * 128 + (lane >> 3)) * g.ldo + wc * 64) * esz + (lane & 7) * 16;
             // readfirstlane: the tile origin comes out of an integer division done on the VALU; without it hipcc wraps every
             // buffer op in a waterfall loop over the (uniform) SGPR offset
-            pp_epilogue_full<T, EPI>(g, acc, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz,
-                                     __builtin_amdgcn_readfirstlane(n0 + wc * 64), lane);
+            pp_epilogue_full<T, EPI, (FLAGS & 16384) != 0>(acc, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
             relaxed = true;
         } else {
             const int row0 = m0 + wr * 128 + l31, ncol = n0 + wc * 64;
@@ -456,6 +480,8 @@ static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t 
         case 256: return launch_pp_inst<T, EPI_BIAS, 256>(a, n_cu, stream, prepare);
         case 512: return launch_pp_inst<T, EPI_BIAS, 512>(a, n_cu, stream, prepare);
         case 1024: return launch_pp_inst<T, EPI_BIAS, 1024>(a, n_cu, stream, prepare);
+        case 2048: return launch_pp_inst<T, EPI_BIAS, 2048>(a, n_cu, stream, prepare);
+        case 16384: return launch_pp_inst<T, EPI_BIAS, 16384>(a, n_cu, stream, prepare);
         case 1028: return launch_pp_inst<T, EPI_BIAS, 1028>(a, n_cu, stream, prepare);
         case 1032: return launch_pp_inst<T, EPI_BIAS, 1032>(a, n_cu, stream, prepare);
         case 1036: return launch_pp_inst<T, EPI_BIAS, 1036>(a, n_cu, stream, prepare);
