@@ -147,10 +147,29 @@ int vitx_op_layernorm(int dtype, const void *d_x, const void *d_w, const void *d
  *   epi 3: out f32    = acc + bias                  (vit.cpp:927-928)
  * M must be a multiple of 128 rows allocated; N, K multiples of 64. */
 int vitx_op_gemm(int dtype, int epi, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int M, int N, int K, void *stream);
+/* The same with an explicit kernel family, so every production GEMM variant can be checked against a numeric reference:
+ *   kernel 0 = automatic (what the forward would pick for this shape), 1 = ping-pong persistent 256x256 kernel (gemm_pp.hip),
+ *   945 / 445 = ring kernels with 256x256 tiles (persistent / one workgroup per tile), 245 = 128x256, 122 = skinny 64x128,
+ *   2 = the automatic choice with the tail split forced on (rows of a partial round re-tiled 128x256 in a second launch).
+ * Adds epi 4 (patch embedding, vit.cpp:772-797): out f32 [M + M/tpi + 1 rows] : row m -> row m + m/tpi + 1, + d_pos[(m % tpi) + 1][n];
+ * d_pos is [tpi + 1][N] f32 and is ignored by the other epilogues.  M_real <= M rows are stored (M is the padded row count).
+ * d_w and d_bias must hold N rounded up to a multiple of 256 rows (zeros beyond N).
+ * VITX_ERR_UNSUPPORTED when the chosen kernel cannot tile the shape. */
+int vitx_op_gemm_ex(int dtype, int epi, int kernel, const void *d_a, const void *d_w, const void *d_bias, void *d_out, const void *d_pos,
+                    int M, int M_real, int N, int K, int tpi, void *stream);
 /* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
 int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* probs = softmax(logits) over num_classes with the reference's fp16 exp rounding (vit.cpp:931). */
 int vitx_op_softmax(const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);
+/* The same with the rounding type of the exp explicit (VITX_F16 = the reference's LUT semantics, VITX_BF16 = the bf16 engine). */
+int vitx_op_softmax_dt(int dtype, const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);
+
+/* ---- residual-stream trace (parity localisation) ------------------------------ */
+/* After vitx_trace_enable(ctx, ids, n) every forward also copies the f32 residual stream X of images ids[0..n) -- after the
+ * patch embedding and after each encoder layer -- into a device buffer; vitx_trace_read() synchronises and returns it as
+ * [L + 1][n][tokens][hidden] f32 (vit.cpp:797 and :900: the tensor `cur` carries between blocks).  n = 0 disables. */
+int vitx_trace_enable(vitx_ctx *c, const int32_t *image_ids, int n);
+int vitx_trace_read(vitx_ctx *c, float *out, size_t n_floats);
 
 #ifdef __cplusplus
 }

@@ -18,13 +18,14 @@ LIB_PATH = os.environ.get("VITX_LIB") or os.path.join(_HERE, "libvitx.so")   # V
 
 F16, BF16 = 0, 1
 BICUBIC, BILINEAR = 0, 1
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32 = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH = 0, 1, 2, 3, 4
+GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT = 0, 1, 2          # vitx_op_gemm_ex `kernel` (or a ring configuration: 945, 445, 245, 122)
 
 EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
-    "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_attention", "vitx_op_softmax",
+    "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
 ]
 
 
@@ -84,6 +85,10 @@ def lib():
         L.vitx_op_gemm.argtypes = [ip, ip, vp, vp, vp, vp, ip, ip, ip, vp]
         L.vitx_op_attention.argtypes = [ip, vp, vp, ip, ip, ip, ip, vp]
         L.vitx_op_softmax.argtypes = [vp, vp, ip, ip, ip, vp]
+        L.vitx_op_softmax_dt.argtypes = [ip, vp, vp, ip, ip, ip, vp]
+        L.vitx_op_gemm_ex.argtypes = [ip, ip, ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+        L.vitx_trace_enable.argtypes = [vp, C.POINTER(C.c_int32), ip]
+        L.vitx_trace_read.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t]
         _lib = L
     return _lib
 
@@ -186,6 +191,20 @@ class Context:
     def forward_device(self, d_imgs: int, n: int, d_probs: int, d_logits: int = 0, stream: int = 0) -> None:
         """Device pointers; only enqueues on `stream` (0 = the context's own stream)."""
         check(lib().vitx_forward_device(self._h, d_imgs, n, d_probs, d_logits or None, stream or None), "vitx_forward_device")
+
+    def trace_enable(self, image_ids) -> None:
+        """Record the f32 residual stream of these images after the patch embedding and after every layer (vitx_trace_enable)."""
+        ids = (C.c_int32 * len(image_ids))(*image_ids)
+        check(lib().vitx_trace_enable(self._h, ids, len(image_ids)), "vitx_trace_enable")
+        self._trace_n = len(image_ids)
+
+    def trace_read(self) -> np.ndarray:
+        """[L + 1, n_ids, tokens, hidden] f32 of the last forward."""
+        hp = self.model.hparams
+        N = (hp.img_size // hp.patch_size) ** 2 + 1
+        out = np.empty((hp.num_hidden_layers + 1, self._trace_n, N, hp.hidden_size), np.float32)
+        check(lib().vitx_trace_read(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "vitx_trace_read")
+        return out
 
     def synchronize(self) -> None:
         check(lib().vitx_ctx_synchronize(self._h), "vitx_ctx_synchronize")

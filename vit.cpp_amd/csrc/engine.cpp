@@ -81,6 +81,9 @@ struct vitx_ctx {
     float *img = nullptr;        // [max_batch][S][S][3] staging for the host entry point
     float *probs = nullptr;      // [max_batch][C]
     float *logits_all = nullptr; // [max_batch][C] staging for the host entry point
+    // residual-stream trace (vitx_trace_enable)
+    std::vector<int> trace_ids;
+    float *trace_buf = nullptr;  // [L + 1][n_ids][N][D]
     // profiling
     bool prof_on = false;
     hipEvent_t prof_base = nullptr;
@@ -95,6 +98,7 @@ struct vitx_ctx {
         for (auto &sl : slices) { if (sl.stream) (void)hipStreamDestroy(sl.stream); if (sl.done) (void)hipEventDestroy(sl.done); }
         if (fork) (void)hipEventDestroy(fork);
         if (prof_base) (void)hipEventDestroy(prof_base);
+        if (trace_buf) (void)hipFree(trace_buf);
         for (void *p : allocs) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -267,7 +271,17 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
 void vitx_ctx_free(vitx_ctx *c) { delete c; }
 int vitx_ctx_max_batch(const vitx_ctx *c) { return c ? c->max_batch : 0; }
 
-static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const void *d_imgs, int n, void *d_probs, void *d_logits) {
+static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const void *d_imgs, int first_img, int n, void *d_probs, void *d_logits) {
+    // residual-stream trace: copy X of the traced images that live in this sub-batch (stage 0 = after patch embedding, il + 1 = after layer il)
+    auto trace = [&](int stage) -> int {
+        const size_t per = (size_t)c->N * c->D;
+        for (size_t k = 0; k < c->trace_ids.size(); ++k) {
+            const int id = c->trace_ids[k];
+            if (id < first_img || id >= first_img + n) continue;
+            HIP_TRY(hipMemcpyAsync(c->trace_buf + ((size_t)stage * c->trace_ids.size() + k) * per, sl.X + (size_t)(id - first_img) * per, per * 4, hipMemcpyDeviceToDevice, st));
+        }
+        return VITX_OK;
+    };
     const int D = c->D, N = c->N, tm = c->tm, tn = c->tn, dt = c->dtype;
     const int tpi = c->g * c->g;
     const int Mp_real = n * tpi, Mp = round_up(Mp_real, tm);       // patch rows
@@ -286,6 +300,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         ProfScope ps(c, st, PC_CLS, 0, (double)n * D * 4);
         HIP_TRY(launch_cls_rows(c->cls, c->pos, sl.X, n, N, D, st));
     }
+    if (!c->trace_ids.empty() && (rc = trace(0))) return rc;
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
         {   // norm1 (vit.cpp:808-812)
@@ -307,6 +322,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         // MLP (vit.cpp:889-900)
         if ((rc = gemm(c, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, w.fc1_w, w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2))) return rc;
         if ((rc = gemm(c, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, w.fc2_w, w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4))) return rc;
+        if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D
     {
@@ -375,7 +391,7 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     // event pair brackets one kernel running alone (exclusive durations, comparable with rocprofv3 --stats)
     const bool serial = c->prof_on || c->slices_serial;
     const int ns = (c->nslices > 1 && n >= 8 * c->nslices) ? c->nslices : 1;
-    if (ns == 1) return forward_slice(c, c->slices[0], st, d_imgs, n, d_probs, d_logits);
+    if (ns == 1) return forward_slice(c, c->slices[0], st, d_imgs, 0, n, d_probs, d_logits);
     int m[4];
     split_batch(c, n, ns, m);
     // fork: every slice stream waits for the caller's stream, runs its contiguous sub-batch, and the caller's stream joins
@@ -385,7 +401,7 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
         vitx_ctx::Slice &sl = c->slices[i];
         hipStream_t ss = serial ? st : sl.stream;
         if (!serial) HIP_TRY(hipStreamWaitEvent(sl.stream, c->fork, 0));
-        int rc = forward_slice(c, sl, ss, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, m[i], (float *)d_probs + (size_t)off * c->C,
+        int rc = forward_slice(c, sl, ss, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, off, m[i], (float *)d_probs + (size_t)off * c->C,
                                d_logits ? (float *)d_logits + (size_t)off * c->C : nullptr);
         if (rc) return rc;
         if (!serial) {
@@ -468,18 +484,28 @@ int vitx_op_layernorm(int dtype, const void *x, const void *w, const void *b, vo
     if (e != hipSuccess) { set_error("vitx_op_layernorm: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
     return VITX_OK;
 }
-int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *bias, void *out, int M, int N, int K, void *stream) {
-    if (!a || !w || !out || epi < 0 || epi > 3) return VITX_ERR_ARG;
-    if (M % 128 || N % 64 || K % 64) { set_error("vitx_op_gemm: M %% 128, N %% 64, K %% 64 must be 0"); return VITX_ERR_ARG; }
-    // W (and bias) must hold N rounded up to the 128-row N tile; rows beyond N are never stored
+static int op_gemm_impl(int dtype, int epi, int kernel, const void *a, const void *w, const void *bias, void *out, const void *pos, int M, int M_real, int N, int n_pad, int K, int tpi, void *stream) {
+    if (!a || !w || !out || !bias || epi < 0 || epi > EPI_PATCH || M_real <= 0 || M_real > M || (epi == EPI_PATCH && (!pos || tpi <= 0))) { set_error("vitx_op_gemm_ex: invalid argument"); return VITX_ERR_ARG; }
+    if (M % 128 || N % 4 || K % 64) { set_error("vitx_op_gemm: M %% 128, N %% 4, K %% 64 must be 0"); return VITX_ERR_ARG; }
+    const Tuning *t0 = tuning_for_device(-1);
+    if (!t0) { set_error("vitx_op_gemm: kernel bring-up failed"); return VITX_ERR_HIP; }
+    Tuning t = *t0;
+    if (kernel == 2) t.gemm_split = 1; else if (kernel != 0) t.gemm_cfg = kernel;
+    // W (and bias) must hold n_pad rows; rows beyond N are never stored
     GemmArgs g{};
-    g.A = a; g.W = w; g.bias = (const float *)bias; g.out = out; g.pos = nullptr;
-    g.M = M; g.M_real = M; g.N = N; g.N_pad = round_up(N, gemm_tile_n()); g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = 0;
-    const Tuning *t = tuning_for_device(-1);
-    if (!t) { set_error("vitx_op_gemm: kernel bring-up failed"); return VITX_ERR_HIP; }
-    hipError_t e = launch_gemm(*t, dtype, epi, g, (hipStream_t)stream);
+    g.A = a; g.W = w; g.bias = (const float *)bias; g.out = out; g.pos = (const float *)pos;
+    g.M = M; g.M_real = M_real; g.N = N; g.N_pad = n_pad; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = tpi;
+    hipError_t e = launch_gemm(t, dtype, epi, g, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) { set_error("vitx_op_gemm: kernel %d cannot tile M %d N %d K %d", kernel, M, N, K); return VITX_ERR_UNSUPPORTED; }
     if (e != hipSuccess) { set_error("vitx_op_gemm: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
     return VITX_OK;
+}
+int vitx_op_gemm_ex(int dtype, int epi, int kernel, const void *a, const void *w, const void *bias, void *out, const void *pos, int M, int M_real, int N, int K, int tpi, void *stream) {
+    return op_gemm_impl(dtype, epi, kernel, a, w, bias, out, pos, M, M_real, N, round_up(N, 256), K, tpi, stream);     // W and bias hold N rounded up to 256 rows
+}
+int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *bias, void *out, int M, int N, int K, void *stream) {
+    if (epi < 0 || epi > 3 || N % 64) { set_error("vitx_op_gemm: epi 0..3, N %% 64 == 0"); return VITX_ERR_ARG; }
+    return op_gemm_impl(dtype, epi, 0, a, w, bias, out, nullptr, M, M, N, round_up(N, gemm_tile_n()), K, 0, stream);   // W and bias hold N rounded up to 128 rows
 }
 int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
     if (!qkv || !out || n_img <= 0) return VITX_ERR_ARG;
@@ -489,10 +515,31 @@ int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, i
     if (e != hipSuccess) { set_error("vitx_op_attention: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
     return VITX_OK;
 }
-int vitx_op_softmax(const void *logits, void *probs, int rows, int cols, int ld, void *stream) {
-    if (!logits || !probs || rows <= 0 || cols <= 0) return VITX_ERR_ARG;
-    hipError_t e = launch_softmax(DT_F16, (const float *)logits, (float *)probs, rows, cols, ld, (hipStream_t)stream);
+int vitx_op_softmax_dt(int dtype, const void *logits, void *probs, int rows, int cols, int ld, void *stream) {
+    if (!logits || !probs || rows <= 0 || cols <= 0 || (dtype != VITX_F16 && dtype != VITX_BF16)) return VITX_ERR_ARG;
+    hipError_t e = launch_softmax(dtype, (const float *)logits, (float *)probs, rows, cols, ld, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_softmax: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
+int vitx_op_softmax(const void *logits, void *probs, int rows, int cols, int ld, void *stream) { return vitx_op_softmax_dt(VITX_F16, logits, probs, rows, cols, ld, stream); }
+
+int vitx_trace_enable(vitx_ctx *c, const int32_t *image_ids, int n) {
+    if (!c || n < 0 || (n > 0 && !image_ids)) return VITX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->trace_buf) { (void)hipFree(c->trace_buf); c->trace_buf = nullptr; }
+    c->trace_ids.assign(image_ids, image_ids + n);
+    for (int id : c->trace_ids) if (id < 0 || id >= c->max_batch) { c->trace_ids.clear(); set_error("vitx_trace_enable: image id %d outside 0..%d", id, c->max_batch - 1); return VITX_ERR_ARG; }
+    if (n) HIP_TRY(hipMalloc((void **)&c->trace_buf, (size_t)(c->L + 1) * n * c->N * c->D * 4));
+    return VITX_OK;
+}
+int vitx_trace_read(vitx_ctx *c, float *out, size_t n_floats) {
+    if (!c || !out) return VITX_ERR_ARG;
+    const size_t need = (size_t)(c->L + 1) * c->trace_ids.size() * c->N * c->D;
+    if (!c->trace_buf || n_floats < need) { set_error("vitx_trace_read: trace not enabled or buffer too small (%zu floats needed)", need); return VITX_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, c->trace_buf, need * 4, hipMemcpyDeviceToHost));
     return VITX_OK;
 }
 
