@@ -20,10 +20,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM-side bytes per launch of the GEMM kernels from the separate rocprofv3 --pmc passes committed under profiles/
-# (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); bf16, batch 256.
-HBM_TRAFFIC_GB = {"gemm_fc1_gelu": 0.353, "gemm_qkv_bias": 0.278, "gemm_fc2_resid": 0.334, "gemm_proj_resid": 0.334}   # per logical launch (one sub-batch: persistent kernel + remainder-row kernel); resid: proj/fc2 share kernel symbols (mean)
 PEAK_TFLOPS = 2516.6      # dense bf16/fp16 MFMA, 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH: ~2.5 PF)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+
+
+def load_traffic():
+    """HBM-side bytes per launch of the GEMM classes: NOT measured in this run (PMC counters need their own rocprofv3 passes);
+    read from the committed profiles/hbm_traffic.json, which tools/hbm_traffic.py writes from such passes together with the
+    commit it measured.  Returns ({class: GB per launch}, provenance string) or ({}, None)."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            d = json.load(f)
+        return d.get("gb_per_launch", {}), f"{d.get('source', '?')} @ {d.get('commit', '?')} ({d.get('formula', '')})"
+    except (OSError, ValueError):
+        return {}, None
 
 
 def main():
@@ -83,14 +93,21 @@ def main():
     mean = torch.tensor(pkg.synth.IMAGENET_MEAN); std = torch.tensor(pkg.synth.IMAGENET_STD)
     imgs = ((u8.float() - mean) / std).contiguous().cuda()
     probs = torch.empty((B, C), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    # Everything of a step is enqueued on ONE explicit (non-default) torch stream whose handle the engine gets: the forward, and
+    # after it -- ordered by that stream -- the RCCL all-gather.  (The legacy null stream's handle is 0, which the C ABI reads as
+    # "use the context's own stream": the collective would then race the forward.)
+    st = torch.cuda.Stream()
+    stream = st.cuda_stream
+    assert stream != 0
+    torch.cuda.synchronize()
 
     state = {}
 
     def step():
-        ctx.forward_device(imgs.data_ptr(), B, probs.data_ptr(), 0, stream)
-        if dist is not None:
-            state["all"] = pkg.dist.gather_probs(probs, world * B)     # the one collective: [world*B, C] class probabilities
+        with torch.cuda.stream(st):
+            ctx.forward_device(imgs.data_ptr(), B, probs.data_ptr(), 0, stream)
+            if dist is not None:
+                state["all"] = pkg.dist.gather_probs(probs, world * B)     # the one collective: [world*B, C] class probabilities
 
     for _ in range(args.warmup):
         step()
@@ -127,9 +144,10 @@ def main():
         d_u8 = torch.empty_like(u8, device="cuda")
         imgs2 = torch.empty_like(imgs)
         def fed_step():
-            d_u8.copy_(u8_pinned, non_blocking=True)
-            binding.preprocess_device(d_u8.data_ptr(), B, S, S, S, imgs2.data_ptr(), binding.BICUBIC, stream)
-            ctx.forward_device(imgs2.data_ptr(), B, probs.data_ptr(), 0, stream)
+            with torch.cuda.stream(st):          # copy, preprocess and forward are ordered by the one stream
+                d_u8.copy_(u8_pinned, non_blocking=True)
+                binding.preprocess_device(d_u8.data_ptr(), B, S, S, S, imgs2.data_ptr(), binding.BICUBIC, stream)
+                ctx.forward_device(imgs2.data_ptr(), B, probs.data_ptr(), 0, stream)
         for _ in range(2): fed_step()
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
@@ -138,10 +156,14 @@ def main():
         torch.cuda.synchronize()
         host_feed = B * nfed / (time.perf_counter() - tf0)
         # restore the probabilities of the resident batch for the sanity check below
-        ctx.forward_device(imgs.data_ptr(), B, probs.data_ptr(), 0, stream); torch.cuda.synchronize()
+        step(); torch.cuda.synchronize()
 
     sanity = probs.sum(1)
     assert torch.isfinite(probs).all() and float((sanity - 1).abs().max()) < 1e-3, "forward produced invalid probabilities"
+    if dist is not None:      # the gathered tensor must hold THIS step's local probabilities in this rank's shard
+        mine = state["all"][rank * B:(rank + 1) * B]
+        assert torch.equal(mine, probs), "all-gather returned stale or foreign probabilities for this rank's shard"
+        assert float((state["all"].sum(1) - 1).abs().max()) < 1e-3, "a gathered shard holds invalid probabilities"
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -164,11 +186,11 @@ def main():
             # the sum of the (exclusive) launch durations
             dom = max(gemms, key=lambda p: p["busy_ms"])
             tf = dom["flops"] / (dom["busy_ms"] * 1e-3) / 1e12
+            traffic, traffic_src = load_traffic()
             out["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_TFLOPS, 4), "traffic": HBM_TRAFFIC_GB.get(dom["name"]), "traffic_unit": "GB per launch (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_final_rocprofv3_summary.txt)",
+                               "frac": round(tf / PEAK_TFLOPS, 4), "traffic": traffic.get(dom["name"]), "traffic_unit": "GB per launch",
+                               "traffic_source": traffic_src,
                                "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "flops_per_launch": dom["flops"] / dom["launches"]}
-            if dom["name"] in ("gemm_fc2_resid", "gemm_proj_resid"):
-                out["roofline"]["traffic_note"] = "proj and fc2 run the same kernel symbols: the PMC figure is their mean per logical launch"
             out["roofline"]["launches_per_step"] = dom["launches"] / prof_steps
             out["roofline"]["measured_over"] = f"last {prof_steps} of the {args.steps} timed steps"
             out["roofline"]["schedule"] = "profiled steps: sub-batches serialised on one stream; other steps: 2 sub-batches on 2 HIP streams"

@@ -129,6 +129,13 @@ def test_native_quantize_tool_errors(pkg, binding, tmp_path):
     binding.quantize_file(src, q, 2)
     with pytest.raises(binding.VitxError):
         binding.quantize_file(q, str(tmp_path / "qq.gguf"), 8)   # already quantised input
+    # a failed run leaves nothing behind (validated before the first write, written to a temporary file, renamed on success) ...
+    assert not os.path.exists(str(tmp_path / "qq.gguf")) and not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+    # ... and the input can never be its own output
+    before = open(src, "rb").read()
+    with pytest.raises(binding.VitxError):
+        binding.quantize_file(src, src, 2)
+    assert open(src, "rb").read() == before
 
 
 def _write_raw(path, hp7, labels, tensors):

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <string>
@@ -98,11 +99,20 @@ extern "C" int vitx_quantize_file(const char *path_in, const char *path_out, int
         set_error("vitx_quantize_file: unsupported target type %d (2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0)", ftype);   // quantize.cpp:296-300
         return VITX_ERR_ARG;
     }
+    if (strcmp(path_in, path_out) == 0) { set_error("vitx_quantize_file: input and output are the same file '%s'", path_in); return VITX_ERR_ARG; }
     vitx_model *m = nullptr;
     int rc = vitx_model_load(path_in, &m);
     if (rc != VITX_OK) return rc;
-    FILE *f = fopen(path_out, "wb");
-    if (!f) { set_error("vitx_quantize_file: failed to open '%s' for writing", path_out); vitx_model_free(m); return VITX_ERR_IO; }
+    // validate every tensor BEFORE any byte is written, then write to a temporary file that replaces path_out only on success:
+    // a failure never leaves a truncated model behind
+    for (const HostTensor &t : m->tensors) {
+        if (!(t.n_dims == 2 && ends_with(t.name, "weight"))) continue;
+        if (t.type != T_F32 && t.type != T_F16) { set_error("vitx_quantize_file: tensor '%s' is already quantised (type %d)", t.name.c_str(), t.type); vitx_model_free(m); return VITX_ERR_FORMAT; }
+        if (t.ne[0] % 32) { set_error("vitx_quantize_file: row length %lld of '%s' is not a multiple of 32", (long long)t.ne[0], t.name.c_str()); vitx_model_free(m); return VITX_ERR_FORMAT; }
+    }
+    const std::string tmp = std::string(path_out) + ".tmp" + std::to_string((long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) { set_error("vitx_quantize_file: failed to open '%s' for writing", tmp.c_str()); vitx_model_free(m); return VITX_ERR_IO; }
     auto w32 = [&](int32_t v) { return fwrite(&v, 4, 1, f) == 1; };
     bool ok = w32(0x67676d6c) && w32(m->hp.hidden_size) && w32(m->hp.num_hidden_layers) && w32(m->hp.num_attention_heads) && w32(m->hp.num_classes) &&
               w32(m->hp.patch_size) && w32(m->hp.img_size) && w32(ftype) && w32((int32_t)m->id2label.size());
@@ -133,7 +143,8 @@ extern "C" int vitx_quantize_file(const char *path_in, const char *path_out, int
     }
     if (fclose(f) != 0) ok = false;
     vitx_model_free(m);
-    if (rc != VITX_OK) return rc;
-    if (!ok) { set_error("vitx_quantize_file: short write to '%s'", path_out); return VITX_ERR_IO; }
+    if (rc != VITX_OK) { (void)remove(tmp.c_str()); return rc; }
+    if (!ok) { (void)remove(tmp.c_str()); set_error("vitx_quantize_file: short write to '%s'", tmp.c_str()); return VITX_ERR_IO; }
+    if (rename(tmp.c_str(), path_out) != 0) { (void)remove(tmp.c_str()); set_error("vitx_quantize_file: cannot move the result to '%s'", path_out); return VITX_ERR_IO; }
     return VITX_OK;
 }

@@ -44,11 +44,15 @@ bool vit_image_preprocess(const image_u8 &img, image_f32 &res, const vit_hparams
     return vitx_preprocess_u8(img.data.data(), img.nx, img.ny, S, interp, res.data.data()) == VITX_OK;
 }
 
+// The reference's vit_state carries no weights and can be reused with any model; ours caches a context that does, so the cache
+// is keyed on the parsed model it was built from (vit_model_load frees and replaces that handle on every call).
 static int ensure_ctx(const vit_model &model, vit_state &state, int n) {
-    if (state.ctx && vitx_ctx_max_batch(state.ctx) >= n) return VITX_OK;
-    vitx_ctx_free(state.ctx); state.ctx = nullptr;
+    if (state.ctx && state.ctx_model == model.handle && vitx_ctx_max_batch(state.ctx) >= n) return VITX_OK;
+    vitx_ctx_free(state.ctx); state.ctx = nullptr; state.ctx_model = nullptr;
     state.max_batch = std::max(state.max_batch, n);
-    return vitx_ctx_create(model.handle, state.device, state.max_batch, state.dtype, &state.ctx);
+    const int rc = vitx_ctx_create(model.handle, state.device, state.max_batch, state.dtype, &state.ctx);
+    if (rc == VITX_OK) state.ctx_model = model.handle;
+    return rc;
 }
 
 int vit_predict_batch(const vit_model &model, vit_state &state, const image_f32 *imgs, int n, const vit_params &params,
