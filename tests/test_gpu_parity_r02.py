@@ -307,3 +307,60 @@ def test_forward_large384_full_depth_vs_oracle(pkg, binding, oracle, torch_gpu):
         assert np.abs(probs - rp).max() <= tol, (dt, np.abs(probs - rp).max())
         assert (probs.argmax(1) == rp.argmax(1)).all()
     model.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Attention for any token count (the reference's default hparams are patch 8 = 785 tokens, vit.h:22-28)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_img,N,H", [(1, 785, 2), (2, 300, 1), (1, 250, 3), (3, 225, 2), (1, 1025, 1), (2, 129, 2)])
+def test_streaming_attention_any_token_count(binding, oracle, torch_gpu, n_img, N, H):
+    """Token counts the register-resident kernel is not instantiated for (or cannot hold) run the streaming kernel."""
+    torch = torch_gpu
+    D = H * 64
+    rng = np.random.default_rng(n_img * 100 + N + H)
+    qkv = (rng.standard_normal((n_img * N, 3 * D)) * 0.8).astype(np.float16)
+    ref = oracle.attention(qkv.astype(np.float32), n_img, N, D, H, oracle.REF)
+    dq = _dev(torch, qkv)
+    out = torch.zeros((n_img * N, D), dtype=torch.float16, device="cuda")
+    binding.check(binding.lib().vitx_op_attention_ex(binding.F16, 2, dq.data_ptr(), out.data_ptr(), n_img, N, D, H, None), "attention")
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert np.abs(got - ref).max() <= 3e-3 and np.abs(got - ref).mean() <= 3e-4
+
+
+@pytest.mark.parametrize("N", [197, 577, 50])
+def test_streaming_attention_is_bit_identical_to_single_pass(binding, torch_gpu, N):
+    """Same products, same rounding points, key tiles summed in the same order: the two kernels agree bit for bit."""
+    torch = torch_gpu
+    n_img, H = 2, 3; D = H * 64
+    g = torch.Generator(device="cuda").manual_seed(N)
+    for tdt, dt in ((torch.float16, binding.F16), (torch.bfloat16, binding.BF16)):
+        qkv = (torch.randn((n_img * N, 3 * D), device="cuda", generator=g) * 0.8).to(tdt)
+        outs = []
+        for kernel in (1, 2):
+            out = torch.zeros((n_img * N, D), dtype=tdt, device="cuda")
+            binding.check(binding.lib().vitx_op_attention_ex(dt, kernel, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
+            torch.cuda.synchronize(); outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+
+
+def test_forward_patch8_785_tokens_vs_oracle(pkg, binding, oracle, torch_gpu):
+    """The reference's DEFAULT hparams (patch 8, 785 tokens) used to be refused by vitx_ctx_create: a 2-layer cut of it in F16
+    against the reference semantics at 1e-3, and the full ViT-B/8 at depth 12 on one image."""
+    path = pkg.synth.cached_synthetic("vit_micro_patch8_224", head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(3, 224, seed=8))
+    om = oracle.OracleModel(path)
+    assert om.N == 785
+    rl, rp = om.forward(imgs, oracle.REF)
+    model = binding.Model(path)
+    ctx = binding.Context(model, device=0, max_batch=3, dtype=binding.F16)
+    probs = ctx.forward(imgs); ctx.close(); model.close()
+    assert np.abs(probs - rp).max() <= 1e-3 and (probs.argmax(1) == rp.argmax(1)).all()
+
+    path = pkg.synth.cached_synthetic("vit_base_patch8_224", head_scale=4.0)
+    om = oracle.OracleModel(path)
+    rl, rp = om.forward(imgs[:1], oracle.REF)
+    model = binding.Model(path)
+    ctx = binding.Context(model, device=0, max_batch=1, dtype=binding.F16)
+    probs = ctx.forward(imgs[:1]); ctx.close(); model.close()
+    assert np.abs(probs - rp).max() <= 1e-3 and (probs.argmax(1) == rp.argmax(1)).all()

@@ -25,7 +25,7 @@ EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
-    "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
+    "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
         L.vitx_op_gemm.argtypes = [ip, ip, vp, vp, vp, vp, ip, ip, ip, vp]
         L.vitx_op_attention.argtypes = [ip, vp, vp, ip, ip, ip, ip, vp]
         L.vitx_op_softmax.argtypes = [vp, vp, ip, ip, ip, vp]
+        L.vitx_op_attention_ex.argtypes = [ip, ip, vp, vp, ip, ip, ip, ip, vp]
         L.vitx_op_softmax_dt.argtypes = [ip, vp, vp, ip, ip, ip, vp]
         L.vitx_op_gemm_ex.argtypes = [ip, ip, ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
         L.vitx_trace_enable.argtypes = [vp, C.POINTER(C.c_int32), ip]

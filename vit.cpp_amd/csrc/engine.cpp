@@ -193,7 +193,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     c->C_pad = round_up(c->C, c->tn);
     // validate against what the kernels are actually instantiated for (a context that would fail on its first forward is refused here)
     if (!attention_supports(c->N, c->D, c->H)) {
-        set_error("vitx_ctx_create: %d tokens per image (img_size %d, patch_size %d) is outside the fused attention kernel's instantiations (1-224, 225-256 and 577-608 tokens)", c->N, c->S, c->P);
+        set_error("vitx_ctx_create: attention needs head_dim 64 and at least one token (%d tokens, img_size %d, patch_size %d)", c->N, c->S, c->P);
         return VITX_ERR_UNSUPPORTED;
     }
     if (!layernorm_supports(c->D)) { set_error("vitx_ctx_create: hidden_size %d has no LayerNorm instantiation (64, 128, 192, 256, 384, 512, 768, 1024, 1280, 1536)", c->D); return VITX_ERR_UNSUPPORTED; }
@@ -507,14 +507,18 @@ int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *b
     if (epi < 0 || epi > 3 || N % 64) { set_error("vitx_op_gemm: epi 0..3, N %% 64 == 0"); return VITX_ERR_ARG; }
     return op_gemm_impl(dtype, epi, 0, a, w, bias, out, nullptr, M, M, N, round_up(N, gemm_tile_n()), K, 0, stream);   // W and bias hold N rounded up to 128 rows
 }
-int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
-    if (!qkv || !out || n_img <= 0) return VITX_ERR_ARG;
-    const Tuning *t = tuning_for_device(-1);
-    if (!t) { set_error("vitx_op_attention: kernel bring-up failed"); return VITX_ERR_HIP; }
-    hipError_t e = launch_attention(*t, dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
+int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
+    if (!qkv || !out || n_img <= 0 || kernel < 0 || kernel > 2) return VITX_ERR_ARG;
+    const Tuning *t0 = tuning_for_device(-1);
+    if (!t0) { set_error("vitx_op_attention: kernel bring-up failed"); return VITX_ERR_HIP; }
+    Tuning t = *t0;
+    if (kernel == 2) t.attn_waves = 0;                       // streaming kernel
+    else if (kernel == 1) { if (!attention_single_pass_supports(N)) { set_error("vitx_op_attention: no single-pass instantiation for %d tokens", N); return VITX_ERR_UNSUPPORTED; } if (t.attn_waves == 0) t.attn_waves = 4; }
+    hipError_t e = launch_attention(t, dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_attention: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
     return VITX_OK;
 }
+int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) { return vitx_op_attention_ex(dtype, 0, qkv, out, n_img, N, D, H, stream); }
 int vitx_op_softmax_dt(int dtype, const void *logits, void *probs, int rows, int cols, int ld, void *stream) {
     if (!logits || !probs || rows <= 0 || cols <= 0 || (dtype != VITX_F16 && dtype != VITX_BF16)) return VITX_ERR_ARG;
     hipError_t e = launch_softmax(dtype, (const float *)logits, (float *)probs, rows, cols, ld, (hipStream_t)stream);

@@ -59,7 +59,8 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_i
 hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream);
 // fused per-(image,head) attention  (vit.cpp:826-866)
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream);
-bool attention_supports(int N, int D, int H);     // instantiation table of the fused kernel
+bool attention_supports(int N, int D, int H);     // head_dim 64, any token count
+bool attention_single_pass_supports(int N);       // instantiation table of the register-resident kernel
 bool layernorm_supports(int D);
 // class softmax with the reference's fp16 (or bf16) exp rounding (vit.cpp:931)
 hipError_t launch_softmax(int dtype, const float *logits, float *probs, int rows, int cols, int ld, hipStream_t stream);

@@ -519,15 +519,178 @@ static hipError_t launch_attention_t(int attn_waves, const void *qkv, void *out,
     default: return hipErrorInvalidValue;
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Streaming attention for any token count (vit.cpp:826-866; the reference's DEFAULT hparams are patch 8 = 785 tokens,
+// vit.h:22-28): the single-pass kernel above keeps every key tile's scores in registers, which stops at 608 tokens and
+// is only instantiated for the token counts of the /16 models.  Here a workgroup owns 128 queries (4 waves x 32) of one
+// (image, head) and streams the keys through LDS in chunks of CH*32, TWICE:
+//   pass 1  S^T = K Q^T per chunk -> the row maximum over ALL keys (scores are discarded);
+//   pass 2  S^T again, e = round(exp(round(s/8 - max))) with that global maximum -- exactly ggml_soft_max's rounding points,
+//           no online rescaling -- row sum of the rounded e, O^T += V^T P^T; normalise at the end.
+// Recomputing QK^T costs 50 % more MFMA work than an online softmax, and keeps the numerics identical to the single-pass
+// kernel (same products, same rounding points, same summation order within a key tile; tiles are summed in order).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CH>
+__global__ __launch_bounds__(256, 2) void attention_stream_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int qblocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 256, CK = CH * 32, VLD = CK + 8;
+    char *Ks = smem;
+    T *VT = (T *)(smem + CK * 128);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qb = blockIdx.x % qblocks, bh = blockIdx.x / qblocks;
+    const int b = bh / H, h = bh % H;
+    const T *base = qkv + (size_t)b * N * 3 * D + h * 64;
+    typedef typename Elem<T>::v8 v8;
+    const int nchunks = (N + CK - 1) / CK;
+
+    const int qrow = qb * 128 + wave * 32 + l31;
+    const bool qvalid = qrow < N;
+    v8 qf[4];
+    {
+        const int qr = min(qrow, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qr * 3 * D + ks * 16 + hh * 8);
+    }
+    auto stage_k = [&](int key0) {
+        constexpr int IT = (CK * 8 + NT - 1) / NT;
+        v8 kv[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid, key = key0 + (c >> 3), sl = c & 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kv[it][j] = (T)0.0f;
+            if (c < CK * 8 && key < N) kv[it] = *(const v8 *)(base + (size_t)key * 3 * D + D + sl * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid;
+            if (c < CK * 8) *(v8 *)(Ks + swz_byte(c >> 3, c & 7)) = kv[it];
+        }
+    };
+    auto stage_vt = [&](int key0) {      // V^T [64][CK + 8]; keys 4-7 <-> 8-11 of every 16 swapped (MFMA k-slot order of the P registers)
+        constexpr int NP = CK / 2, ITEMS = NP * 8, IT = (ITEMS + NT - 1) / NT;
+        v8 va[IT], vb[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid, pr = c % NP, sl = c / NP, key = key0 + 2 * pr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { va[it][j] = (T)0.0f; vb[it][j] = (T)0.0f; }
+            if (c < ITEMS && key < N) va[it] = *(const v8 *)(base + (size_t)key * 3 * D + 2 * D + sl * 8);
+            if (c < ITEMS && key + 1 < N) vb[it] = *(const v8 *)(base + (size_t)(key + 1) * 3 * D + 2 * D + sl * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int c = it * NT + tid, pr = c % NP, sl = c / NP, key = 2 * pr;
+            if (c >= ITEMS) continue;
+            const int a = key & 15, q4 = a >> 2, q4s = (q4 == 1) ? 2 : (q4 == 2) ? 1 : q4;
+            const int pos = (key & ~15) | (q4s << 2) | (a & 3);
+            typedef T v2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *(v2 *)(VT + (sl * 8 + j) * VLD + pos) = v2{va[it][j], vb[it][j]};
+        }
+    };
+    auto scores = [&](int kt, int key0, f32x16 &s) {      // one 32-key tile of S^T, padded keys masked
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const v8 kf = *(const v8 *)(Ks + swz_byte(kt * 32 + l31, ks * 2 + hh));
+            s = Elem<T>::mfma(kf, qf[ks], s);
+        }
+        if (key0 + kt * 32 + 32 > N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) s[r] = -INFINITY;
+        }
+    };
+
+    // ---- pass 1: global row maximum of the raw scores
+    float mxs = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) {
+        const int key0 = c * CK;
+        __syncthreads();
+        stage_k(key0);
+        __syncthreads();
+        const int nt = min(CH, (N - key0 + 31) / 32);
+        for (int kt = 0; kt < nt; ++kt) {
+            f32x16 s; scores(kt, key0, s);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mxs = fmaxf(mxs, s[r]);
+        }
+    }
+    mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+    const float nmx = -0.125f * mxs;
+
+    // ---- pass 2: exponentials against the global maximum, row sum of the ROUNDED values, O^T = V^T P^T
+    float sum = 0.0f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+    for (int c = 0; c < nchunks; ++c) {
+        const int key0 = c * CK;
+        __syncthreads();
+        stage_k(key0); stage_vt(key0);
+        __syncthreads();
+        const int nt = min(CH, (N - key0 + 31) / 32);
+        for (int kt = 0; kt < nt; ++kt) {
+            f32x16 s; scores(kt, key0, s);
+            v8 p[2];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[r], 0.125f, nmx), __builtin_fmaf(s[r + 1], 0.125f, nmx));
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[0], 1.44269504f, 0.0f));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[1], 1.44269504f, 0.0f));
+                const typename Pair<T>::v2 eh = round_pair<T>(e0, e1);
+                sum = Pair<T>::sum2(eh, sum);
+                p[r >> 3][r & 7] = eh[0]; p[r >> 3][(r & 7) + 1] = eh[1];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const v8 vf = *(const v8 *)(VT + (dt * 32 + l31) * VLD + kt * 32 + half * 16 + hh * 8);
+                    o[dt] = Elem<T>::mfma(vf, p[half], o[dt]);
+                }
+        }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    if (qvalid) {
+        T *orow = out + ((size_t)b * N + qrow) * D + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                typename Elem<T>::v4 w4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w4[j] = (T)(o[dt][r4 * 4 + j] * inv);
+                *(typename Elem<T>::v4 *)(orow + dt * 32 + r4 * 8 + hh * 4) = w4;
+            }
+    }
+}
+template <typename T>
+static hipError_t launch_attention_stream(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+    constexpr int CH = 8;
+    constexpr int lds = CH * 32 * 128 + 64 * (CH * 32 + 8) * 2;        // 32 KiB + 33 KiB
+    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_stream_kernel<T, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
+    const int qblocks = (N + 127) / 128;
+    hipLaunchKernelGGL((attention_stream_kernel<T, CH>), dim3(n_img * H * qblocks), dim3(256), lds, stream, (const T *)qkv, (T *)out, N, D, H, qblocks);
+    return hipGetLastError();
+}
+
 static const int kAttnNkt[] = {1, 2, 3, 4, 5, 6, 7, 9, 19};      // instantiated key-tile counts (tokens = 32 * nkt, rounded up)
-bool attention_supports(int N, int D, int H) {
-    if (D != H * 64 || N <= 0) return false;
+bool attention_single_pass_supports(int N) {
     const int nkt = (N + 31) / 32;
     for (int k : kAttnNkt) if (k == nkt) return true;
     return false;
 }
+bool attention_supports(int N, int D, int H) { return D == H * 64 && N > 0; }      // any token count: single-pass kernel where instantiated, else the streaming kernel
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
+    if (!attention_single_pass_supports(N) || t.attn_waves == 0)       // VITX_ATTN_WAVES=0 forces the streaming kernel (tests)
+        return dtype == DT_F16 ? launch_attention_stream<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_stream<__bf16>(qkv, out, n_img, N, D, H, stream);
     return dtype == DT_F16 ? launch_attention_t<_Float16>(t.attn_waves, qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(t.attn_waves, qkv, out, n_img, N, D, H, stream);
 }
 
@@ -543,6 +706,7 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
             if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
+        if ((e = (dt == DT_F16 ? launch_attention_stream<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_stream<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
         for (int nkt : kAttnNkt) {
             for (int w : {4, 7}) {
                 if (w == 7 && nkt != 7) continue;
