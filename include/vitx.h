@@ -116,6 +116,17 @@ int vitx_forward(vitx_ctx *c, const float *imgs_hwc, int n, float *probs, float 
 int vitx_forward_device(vitx_ctx *c, const void *d_imgs_hwc, int n, void *d_probs, void *d_logits, void *stream);
 int vitx_ctx_synchronize(vitx_ctx *c);
 
+/* ---- several GPUs in one process (north_star: batch shards + one RCCL gather) -- */
+/* One context (replicated weights) and one host thread per listed device; vitx_group_forward cuts the n host images into
+ * contiguous shards (the first n % n_devices devices take one extra image), runs them concurrently and all-gathers the
+ * [n_local][num_classes] probabilities with ONE ncclAllGather over RCCL; `probs` receives all n rows in image order.
+ * The reference has no counterpart (single image, single device: vit.cpp:747). */
+typedef struct vitx_group vitx_group;
+int vitx_group_create(const vitx_model *m, const int *devices, int n_devices, int max_batch_per_device, int dtype, vitx_group **out);
+void vitx_group_free(vitx_group *g);
+int vitx_group_num_devices(const vitx_group *g);
+int vitx_group_forward(vitx_group *g, const float *imgs_hwc, int n, float *probs);
+
 /* Sorted top-k of one probability row (vit.cpp:1043-1057: descending by prob). */
 int vitx_topk(const float *probs, int num_classes, int k, int32_t *out_idx, float *out_prob);
 

@@ -364,3 +364,37 @@ def test_forward_patch8_785_tokens_vs_oracle(pkg, binding, oracle, torch_gpu):
     ctx = binding.Context(model, device=0, max_batch=1, dtype=binding.F16)
     probs = ctx.forward(imgs[:1]); ctx.close(); model.close()
     assert np.abs(probs - rp).max() <= 1e-3 and (probs.argmax(1) == rp.argmax(1)).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Several GPUs in one process (C ABI: vitx_group_*, RCCL all-gather called from C++)
+# ------------------------------------------------------------------------------------------------------------------
+def test_group_single_device_runs_the_rccl_path(pkg, binding, torch_gpu):
+    """One-GPU box: the group API with one device still goes through ncclCommInitAll + ncclAllGather; ragged batch sizes."""
+    path = pkg.synth.cached_synthetic("vit_tiny_patch16_224", head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(7, 224, seed=77))
+    model = binding.Model(path)
+    ctx = binding.Context(model, device=0, max_batch=8, dtype=binding.F16)
+    want = ctx.forward(imgs); ctx.close()
+    grp = binding.Group(model, [0], 8, binding.F16)
+    for n in (7, 1, 4):
+        assert np.array_equal(grp.forward(imgs[:n]), want[:n])
+    with pytest.raises(binding.VitxError):
+        grp.forward(np.concatenate([imgs, imgs]))           # 14 > 8 per device
+    grp.close(); model.close()
+
+
+def test_group_two_devices_match_one(pkg, binding, torch_gpu):
+    """The REAL engine on two GPUs of one process vs one GPU: shards are contiguous, images independent -> identical rows."""
+    torch = torch_gpu
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs in one process")
+    path = pkg.synth.cached_synthetic("vit_tiny_patch16_224", head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(13, 224, seed=78))
+    model = binding.Model(path)
+    ctx = binding.Context(model, device=0, max_batch=16, dtype=binding.F16)
+    want = ctx.forward(imgs); ctx.close()
+    grp = binding.Group(model, [0, 1], 8, binding.F16)
+    for n in (13, 2, 1):                                     # 13 = 7 + 6 ragged shards; 1 = second device idle
+        assert np.array_equal(grp.forward(imgs[:n]), want[:n])
+    grp.close(); model.close()

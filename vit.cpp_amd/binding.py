@@ -25,7 +25,7 @@ EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
-    "vitx_topk", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
+    "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
 ]
 
 
@@ -78,6 +78,10 @@ def lib():
         L.vitx_forward.argtypes = [vp, C.POINTER(C.c_float), ip, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.vitx_forward_device.argtypes = [vp, vp, ip, vp, vp, vp]
         L.vitx_ctx_synchronize.argtypes = [vp]
+        L.vitx_group_create.argtypes = [vp, C.POINTER(C.c_int), ip, ip, ip, C.POINTER(vp)]
+        L.vitx_group_free.argtypes = [vp]
+        L.vitx_group_num_devices.argtypes = [vp]
+        L.vitx_group_forward.argtypes = [vp, C.POINTER(C.c_float), ip, C.POINTER(C.c_float)]
         L.vitx_topk.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.vitx_profile_enable.argtypes = [vp, ip]
         L.vitx_profile_read.argtypes = [vp, C.POINTER(ProfEntry), ip, C.POINTER(ip)]
@@ -217,6 +221,33 @@ class Context:
         arr = (ProfEntry * 16)(); n = C.c_int()
         check(lib().vitx_profile_read(self._h, arr, 16, C.byref(n)), "vitx_profile_read")
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, flops=arr[i].flops, bytes=arr[i].bytes, busy_ms=arr[i].busy_ms) for i in range(n.value)]
+
+
+class Group:
+    """Several GPUs in one process: batch shards + one RCCL all-gather of the probabilities (vitx_group_*)."""
+
+    def __init__(self, model: Model, devices, max_batch_per_device: int, dtype: int = F16):
+        self.model = model
+        devs = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        check(lib().vitx_group_create(model._h, devs, len(devices), max_batch_per_device, dtype, C.byref(self._h)), "vitx_group_create")
+
+    def forward(self, imgs_hwc: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(imgs_hwc, np.float32); n = x.shape[0]
+        probs = np.empty((n, self.model.num_classes), np.float32)
+        fp = C.POINTER(C.c_float)
+        check(lib().vitx_group_forward(self._h, x.ctypes.data_as(fp), n, probs.ctypes.data_as(fp)), "vitx_group_forward")
+        return probs
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h:
+            lib().vitx_group_free(self._h); self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def topk(probs_row: np.ndarray, k: int = 5):
