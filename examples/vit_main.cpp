@@ -2,27 +2,13 @@
 // header vit.cpp_amd/vit.h: vit_params_parse -> vit_model_load -> load image -> vit_image_preprocess -> vit_predict,
 // same stdout / stderr lines.  Differences a maintainer would see when switching main.cpp over:
 //   * no ggml_init / ggml_free: vit_state owns an engine context that vit_predict creates on first use;
-//   * load_image_from_file is stb_image in the reference (inside the absent ggml tree); this example reads binary
-//     PPM (P6, maxval 255) so that it has no third-party dependency -- decode JPEG/PNG with any library and fill image_u8.
+//   * load_image_from_file (stb_image in the reference, inside the absent ggml tree) is libvitx.so's own JPEG / PNG / PPM decoder.
 // Build:  g++ -std=c++17 -O2 examples/vit_main.cpp -Ivit.cpp_amd -Lvit.cpp_amd -lvitx -Wl,-rpath,$PWD/vit.cpp_amd -o vit
 #include <chrono>
 #include <cstdio>
 #include <cstring>
-#include <fstream>
 
 #include "vit.h"
-
-static bool load_ppm(const std::string &fname, image_u8 &img) {
-    std::ifstream f(fname, std::ios::binary);
-    if (!f) return false;
-    std::string magic; int maxval = 0;
-    auto skip = [&]() { for (;;) { int c = f.peek(); if (c == '#') { std::string l; std::getline(f, l); } else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') f.get(); else break; } };
-    f >> magic; skip(); f >> img.nx; skip(); f >> img.ny; skip(); f >> maxval; f.get();
-    if (magic != "P6" || maxval != 255 || img.nx <= 0 || img.ny <= 0) return false;
-    img.data.resize((size_t)img.nx * img.ny * 3);
-    f.read(reinterpret_cast<char *>(img.data.data()), (std::streamsize)img.data.size());
-    return (size_t)f.gcount() == img.data.size();
-}
 
 int main(int argc, char **argv) {
     const auto t_main_start = std::chrono::steady_clock::now();
@@ -46,7 +32,7 @@ int main(int argc, char **argv) {
     }
     const double t_load_ms = ms_since(t_load_start);
 
-    if (!load_ppm(params.fname_inp, img0)) {                            // main.cpp:69-73
+    if (!load_image_from_file(params.fname_inp.c_str(), img0)) {        // main.cpp:67-73
         fprintf(stderr, "%s: failed to load image from '%s'\n", __func__, params.fname_inp.c_str());
         return 1;
     }

@@ -83,6 +83,14 @@ int vitx_model_tensor_f32(const vitx_model *m, int index, float *out, size_t n_e
  * encoders).  Host only.  VITX_ERR_ARG for another ftype, VITX_ERR_FORMAT if already quantised. */
 int vitx_quantize_file(const char *path_in, const char *path_out, int ftype);
 
+/* ---- image files (replaces load_image_from_file = stbi_load(..., 3), vit.cpp:109-127) ---- */
+/* Decodes a JPEG (baseline or progressive Huffman, 8-bit, gray or YCbCr), a non-interlaced PNG or a binary PPM into tightly
+ * packed RGB u8 [ny][nx][3], top row first -- what stbi_load(fname, &nx, &ny, &nc, 3) hands the reference.  *out_rgb is
+ * malloc'ed; release it with vitx_image_free.  VITX_ERR_IO if the file cannot be read, VITX_ERR_FORMAT if it cannot be decoded. */
+int vitx_image_load(const char *path, uint8_t **out_rgb, int *nx, int *ny);
+int vitx_image_decode(const uint8_t *bytes, size_t n_bytes, uint8_t **out_rgb, int *nx, int *ny);
+void vitx_image_free(uint8_t *rgb);
+
 /* ---- preprocess (replaces vit_image_preprocess, vit.cpp:289-305) ------------ */
 /* u8 HWC RGB [ny][nx][3] -> f32 HWC [img_size][img_size][3], resized without
  * crop/antialias, rounded to u8, ImageNet mean/std normalised (vit.cpp:130-287). */

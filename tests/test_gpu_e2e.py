@@ -293,3 +293,16 @@ def test_cpp_example_main_runs_like_the_reference_cli(pkg, binding, oracle, torc
         label, prob = l[3:].rsplit(" : ", 1)
         assert label == m.label(int(i)) and abs(float(prob) - rp[0][i]) <= 0.011
     assert "processed, out dims : (224 x 224)" in r.stderr and "total time" in r.stderr
+    # the same binary straight on the (progressive) JPEG: load_image_from_file decodes it inside libvitx.so (vit.cpp:109-127);
+    # its top-5 must agree with the oracle fed the SAME decoded bytes
+    jpg = os.path.join(root, "tests", "golden", "assets", "tench.jpg")
+    r = subprocess.run([exe, "-m", path, "-i", jpg, "-k", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "loaded image" in r.stderr and "(612 x 408)" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith(" > ")]
+    ours = binding.load_image(jpg)
+    _, rp2 = oracle.OracleModel(path).forward(oracle.preprocess(ours, 224, "bicubic")[None], oracle.REF)
+    order2 = np.argsort(-rp2[0], kind="stable")[:5]
+    for l, i in zip(lines, order2):
+        label, prob = l[3:].rsplit(" : ", 1)
+        assert label == m.label(int(i)) and abs(float(prob) - rp2[0][i]) <= 0.011

@@ -23,7 +23,7 @@ GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT = 0, 1, 2          # vitx_op_gemm_ex `kernel
 
 EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
-    "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
+    "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_image_load", "vitx_image_decode", "vitx_image_free", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
 ]
@@ -70,6 +70,9 @@ def lib():
         L.vitx_model_tensor_info.argtypes = [vp, ip, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_size_t)]
         L.vitx_model_tensor_f32.argtypes = [vp, ip, C.POINTER(C.c_float), C.c_size_t]
         L.vitx_quantize_file.argtypes = [C.c_char_p, C.c_char_p, ip]
+        L.vitx_image_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(ip), C.POINTER(ip)]
+        L.vitx_image_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(ip), C.POINTER(ip)]
+        L.vitx_image_free.argtypes = [C.POINTER(C.c_uint8)]
         L.vitx_preprocess_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, ip, C.POINTER(C.c_float)]
         L.vitx_preprocess_u8_device.argtypes = [vp, ip, ip, ip, ip, ip, vp, vp]
         L.vitx_ctx_create.argtypes = [vp, ip, ip, ip, C.POINTER(vp)]
@@ -151,6 +154,25 @@ class Model:
 def quantize_file(path_in: str, path_out: str, ftype: int) -> None:
     """Native `quantize` (quantize.cpp:34-353): f16/f32 file -> q4_0/q4_1/q5_0/q5_1/q8_0 file."""
     check(lib().vitx_quantize_file(path_in.encode(), path_out.encode(), ftype), "vitx_quantize_file")
+
+
+def load_image(path: str) -> np.ndarray:
+    """load_image_from_file (vit.cpp:109-127): JPEG / PNG / PPM file -> HWC u8 RGB, decoded by libvitx.so itself."""
+    data = C.POINTER(C.c_uint8)(); nx = C.c_int(); ny = C.c_int()
+    check(lib().vitx_image_load(path.encode(), C.byref(data), C.byref(nx), C.byref(ny)), f"vitx_image_load({path})")
+    try:
+        return np.ctypeslib.as_array(data, shape=(ny.value, nx.value, 3)).copy()
+    finally:
+        lib().vitx_image_free(data)
+
+
+def decode_image(blob: bytes) -> np.ndarray:
+    data = C.POINTER(C.c_uint8)(); nx = C.c_int(); ny = C.c_int()
+    check(lib().vitx_image_decode(blob, len(blob), C.byref(data), C.byref(nx), C.byref(ny)), "vitx_image_decode")
+    try:
+        return np.ctypeslib.as_array(data, shape=(ny.value, nx.value, 3)).copy()
+    finally:
+        lib().vitx_image_free(data)
 
 
 def preprocess(img_u8: np.ndarray, img_size: int, interp: int = BICUBIC) -> np.ndarray:

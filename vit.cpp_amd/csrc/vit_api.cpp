@@ -7,6 +7,19 @@
 vit_model::~vit_model() { vitx_model_free(handle); }
 vit_state::~vit_state() { vitx_ctx_free(ctx); }
 
+// vit.cpp:109-127 -- false + message on stderr when the file cannot be read or decoded
+bool load_image_from_file(const std::string &fname, image_u8 &img) {
+    uint8_t *data = nullptr; int nx = 0, ny = 0;
+    if (vitx_image_load(fname.c_str(), &data, &nx, &ny) != VITX_OK) {
+        fprintf(stderr, "%s: failed to load '%s'\n", __func__, fname.c_str());
+        return false;
+    }
+    img.nx = nx; img.ny = ny;
+    img.data.assign(data, data + (size_t)nx * ny * 3);
+    vitx_image_free(data);
+    return true;
+}
+
 // vit.cpp:308-712 -- false + message on stderr for any error
 bool vit_model_load(const std::string &fname, vit_model &model) {
     printf("%s: loading model from '%s' - please wait\n", __func__, fname.c_str());

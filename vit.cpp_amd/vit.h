@@ -1,8 +1,9 @@
 // vit.h -- C++ drop-in mirror of the reference's public API for the forward path.
 //
 // Same entry-point names, argument meaning and error behaviour as
-// /root/reference/vit.h:115-124, re-declared so existing callers (main.cpp:57-98,
-// tests/benchmark.cpp:57-122) compile unchanged against libvitx.so:
+// /root/reference/vit.h:115-124, re-declared so the reference's callers (main.cpp:57-98, tests/benchmark.cpp:57-122) build
+// against libvitx.so once their ggml lines are removed (main.cpp:82-91 creates state.ctx / state.prediction by hand and :110
+// frees model.ctx -- ggml objects this engine does not have; examples/vit_main.cpp is main.cpp without them):
 //   * vit_model / vit_state keep their names but hold opaque engine handles instead of
 //     ggml_tensor* / ggml_context* (the reference's fields are ggml internals);
 //   * vit_predict still fills `predictions` with all (prob, class) pairs sorted
@@ -74,6 +75,7 @@ struct vit_params {                       // vit.h:105-113
     float eps = 1e-6f;                    // parsed but unused by the forward, as in the reference (vit.cpp:984-987 vs 808)
 };
 
+bool load_image_from_file(const std::string &fname, image_u8 &img);                                    // vit.h:118 (stbi_load replaced by csrc/image_decode.cpp)
 bool vit_model_load(const std::string &fname, vit_model &model);                                       // vit.h:120
 bool vit_image_preprocess(const image_u8 &img, image_f32 &res, const vit_hparams &params);            // vit.h:119
 int vit_predict(const vit_model &model, vit_state &state, const image_f32 img1, const vit_params &params,
