@@ -55,6 +55,7 @@ struct vitx_ctx {
     const Tuning *tune = nullptr;        // per-device launch parameters (CU count, kernel selection), immutable
     int split_override[4] = {0, 0, 0, 0};  // VITX_SPLIT, parsed at creation
     bool slices_serial = false;          // VITX_SLICES_SERIAL, parsed at creation
+    int skip = 0;                        // VITX_SKIP (upper-bound experiments only; results are garbage): 1 = no attention, 2 = no per-layer LayerNorm
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     // weights
@@ -74,6 +75,7 @@ struct vitx_ctx {
         float *logits = nullptr;     // [Bpad][C_pad]
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        Tuning tune;                 // the device's tuning with n_cu = the CUs this slice's stream may use (CU-masked streams)
     };
     int nslices = 1;
     std::vector<Slice> slices;
@@ -158,7 +160,7 @@ struct ProfScope {
     ~ProfScope() { if (on) (void)hipEventRecord(c->recs[idx].b, s); }
 };
 
-int gemm(vitx_ctx *c, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
+int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
          int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes) {
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
@@ -166,7 +168,7 @@ int gemm(vitx_ctx *c, hipStream_t st, int pc, int epi, const void *A, const void
     double bytes = (double)M_real * K * 2 + (double)N * K * 2 + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
     ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
-    HIP_TRY(launch_gemm(*c->tune, c->dtype, epi, a, st));
+    HIP_TRY(launch_gemm(tune, c->dtype, epi, a, st));
     return VITX_OK;
 }
 
@@ -203,7 +205,8 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         int i = 0;
         for (const char *p = e; i < 3 && *p; ++i) { c->split_override[i] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
     }
-    c->slices_serial = getenv("VITX_SLICES_SERIAL") != nullptr;     // for rocprofv3 runs that should match the profiled steps
+    c->slices_serial = getenv("VITX_SLICES_SERIAL") != nullptr;
+    if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);     // for rocprofv3 runs that should match the profiled steps
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
     const int D = c->D, tn = c->tn;
@@ -254,6 +257,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
         if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
+        sl.tune = *c->tune;
         if (ns > 1) {
             HIP_TRY(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
@@ -284,6 +288,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     };
     const int D = c->D, N = c->N, tm = c->tm, tn = c->tn, dt = c->dtype;
     const int tpi = c->g * c->g;
+    const Tuning &tn_ = (st == sl.stream && sl.stream) ? sl.tune : *c->tune;      // serialised / single-slice runs use the whole chip
     const int Mp_real = n * tpi, Mp = round_up(Mp_real, tm);       // patch rows
     const int M_real = n * N, M = round_up(M_real, tm);            // token rows
     const double eb = 2.0;                                          // operand bytes
@@ -294,7 +299,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         HIP_TRY(launch_patchify(dt, (const float *)d_imgs, sl.Hbuf, n, c->S, c->P, c->Kpe_pad, Mp, st));
     }
     int rc;
-    if ((rc = gemm(c, st, PC_GEMM_PATCH, EPI_PATCH, sl.Hbuf, c->pe_w, c->pe_b, sl.X, c->pos, Mp, Mp_real, D, round_up(D, tn), c->Kpe_pad,
+    if ((rc = gemm(c, tn_, st, PC_GEMM_PATCH, EPI_PATCH, sl.Hbuf, c->pe_w, c->pe_b, sl.X, c->pos, Mp, Mp_real, D, round_up(D, tn), c->Kpe_pad,
                    c->Kpe_pad, c->Kpe_pad, D, tpi, 4))) return rc;
     {
         ProfScope ps(c, st, PC_CLS, 0, (double)n * D * 4);
@@ -305,23 +310,23 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         const LayerW &w = c->layers[il];
         {   // norm1 (vit.cpp:808-812)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
-            HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
+            if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // qkv projection (vit.cpp:820-821)
-        if ((rc = gemm(c, st, PC_GEMM_QKV, EPI_BIAS, sl.U, w.qkv_w, w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, w.qkv_w, w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
-            HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
+            if (!(c->skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873)
-        if ((rc = gemm(c, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, w.proj_w, w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, w.proj_w, w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4))) return rc;
         {   // norm2 (vit.cpp:881-885)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
-            HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
+            if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // MLP (vit.cpp:889-900)
-        if ((rc = gemm(c, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, w.fc1_w, w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2))) return rc;
-        if ((rc = gemm(c, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, w.fc2_w, w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, w.fc1_w, w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, w.fc2_w, w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4))) return rc;
         if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D
@@ -332,7 +337,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     // classifier (vit.cpp:927-928) and class softmax (vit.cpp:931-933)
     float *lg = d_logits ? (float *)d_logits : sl.logits;
     const int ldl = d_logits ? c->C : c->C_pad;
-    if ((rc = gemm(c, st, PC_GEMM_HEAD, EPI_BIAS_F32, sl.Z, c->head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4))) return rc;
+    if ((rc = gemm(c, tn_, st, PC_GEMM_HEAD, EPI_BIAS_F32, sl.Z, c->head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4))) return rc;
     {
         ProfScope ps(c, st, PC_SOFTMAX, 0, (double)n * c->C * 8);
         HIP_TRY(launch_softmax(dt, lg, (float *)d_probs, n, c->C, ldl, st));

@@ -29,13 +29,24 @@
 #include "device_common.h"
 #include "kernels.h"
 
+// Register cap of the kernel (hipcc doubles amdgpu_num_vgpr on gfx90a+: arch + accumulator halves, so 128 = all 256 registers of a
+// 2-waves-per-SIMD kernel).  r02 experiment: 116 (= 232) leaves 48 VGPRs per SIMD free, exactly one LayerNorm wave, so the other
+// sub-batch stream's LayerNorm could co-reside with a persistent GEMM -- measured 2.7 % SLOWER on the whole forward
+// (10.91 vs 10.61 ms/step, interleaved A/B): the spills it forces cost more than the overlap buys.
+#ifndef PP_MAX_VGPR
+#define PP_MAX_VGPR 128
+#endif
+
 namespace vitx {
 
 namespace pp {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 16384;             // one half-tile image: 128 rows x 128 B
-constexpr int BUF = 4 * HALF;           // [A0 | A1 | B0 | B1]
-constexpr int LDS = 2 * BUF;            // 128 KiB operand ring
+constexpr int LDS = 8 * HALF;           // 128 KiB operand ring: [A0 A1 of buffer 0 | A0 A1 of buffer 1 | B0 B1 of buffer 0 | B0 B1 of buffer 1]
+// all four A half-tiles lie in the first 64 KiB and all four B half-tiles in the second, so every fragment read is
+// "one per-lane base register + a 16-bit immediate": no per-buffer address copies (8 VGPRs and 8 adds per K-tile less)
+__host__ __device__ constexpr int off_a(int buf, int h) { return (buf * 2 + h) * HALF; }
+__host__ __device__ constexpr int off_b(int buf, int h) { return (4 + buf * 2 + h) * HALF; }
 constexpr int LDS_ALL = LDS + 8 * 4096; // + one 4 KiB epilogue patch per wave = all 160 KiB
 constexpr int GROUP_M = 8;
 constexpr int STAGE_OPS = 2;            // LDS-DMA instructions per thread per half-tile
@@ -148,13 +159,12 @@ __device__ __forceinline__ void pp_epilogue_full(f32x16 (&acc)[4][2], __amdgpu_b
                 w[q] = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
             }
         };
-        u32x2 w[2][8];
-        compute(0, w[0]);
+        u32x2 w[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            compute(i, w);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) *(u32x2 *)(patch + wr_row + ((q * 16) ^ x16) + hh * 8) = w[i & 1][q];
-            if (i + 1 < 4) compute(i + 1, w[(i + 1) & 1]);
+            for (int q = 0; q < 8; ++q) *(u32x2 *)(patch + wr_row + ((q * 16) ^ x16) + hh * 8) = w[q];
             pp_lds_fence();
             u32x4 d[4];
 #pragma unroll
@@ -203,7 +213,7 @@ __device__ __forceinline__ void pp_epilogue_full(f32x16 (&acc)[4][2], __amdgpu_b
 // 2048 = no epilogue at all, 512 = epilogue stores drained (no counted skip), 4 = no LDS-DMA in the loop, 8 = no fragment reads, 16 = no MFMAs, 32 = s_memtime stamp after every barrier of K-tiles 4..7 of
 // the first tile (written to g.pos as [block][wave][64] u32)
 template <typename T, int EPI, int FLAGS>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR))) void gemm_pp_kernel(GemmArgs g) {
     using namespace pp;
     typedef typename Elem<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         rdA[ks] = swz_byte(wr * 64 + l31, ks * 2 + hh);
-        rdB[ks] = 2 * HALF + swz_byte(wc * 32 + l31, ks * 2 + hh);
+        rdB[ks] = swz_byte(wc * 32 + l31, ks * 2 + hh);
     }
     v8 fa[2][4], fb[2][4];
     f32x16 acc[4][2];
@@ -298,11 +308,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = *(const v8 *)(smem + buf * BUF + h * HALF + ii * 4096 + rdA[ks]);
+            for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = *(const v8 *)(smem + off_a(buf, h) + ii * 4096 + rdA[ks]);
     };
     auto read_b = [&](int buf, int h) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fb[h][ks] = *(const v8 *)(smem + buf * BUF + h * HALF + rdB[ks]);
+        for (int ks = 0; ks < 4; ++ks) fb[h][ks] = *(const v8 *)(smem + off_b(buf, h) + rdB[ks]);
     };
     // MFMAs [first, last) of a quadrant's 8 (k-step major, so consecutive MFMAs alternate between its two accumulators)
     auto mma = [&](int ha, int hb, int first, int last) {
@@ -386,19 +396,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
     auto stage_bias = [&]() { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, LPTR(smem + LDS + wave * 4096), 4, lane * 4, bias_so, 0, 0); };
     auto ktile = [&](auto bc, bool first) {
         constexpr int B = decltype(bc)::value;       // buffer of the K-tile being consumed
-        constexpr int O = (B ^ 1) * BUF, S = B * BUF, W8 = LEAD * STAGE_OPS;
+        constexpr int W8 = LEAD * STAGE_OPS;
         const bool f = B == 0 && first;
-        PP_PHASE((read_a(B, 0), read_b(B, 0)), stage_w(1, O + 3 * HALF), W8, 0, 0, f, (zero_quadrant(0, 0), stage_bias()))   // C00 ; B1 of the next K-tile
-        PP_PHASE(read_b(B, 1), (stage_a(1, O + 1 * HALF), advance()), W8, 0, 1, f, zero_quadrant(0, 1))                        // C01 ; A1 of the next K-tile
-        PP_PHASE(read_a(B, 1), stage_a(0, S + 0 * HALF), W8, 1, 1, f, zero_quadrant(1, 1))                                     // C11 ; A0 two K-tiles ahead
-        PP_PHASE((void)0, stage_w(0, S + 2 * HALF), W8, 1, 0, f, zero_quadrant(1, 0))                                          // C10 ; B0 two K-tiles ahead
+        PP_PHASE((read_a(B, 0), read_b(B, 0)), stage_w(1, off_b(B ^ 1, 1)), W8, 0, 0, f, (zero_quadrant(0, 0), stage_bias()))   // C00 ; B1 of the next K-tile
+        PP_PHASE(read_b(B, 1), (stage_a(1, off_a(B ^ 1, 1)), advance()), W8, 0, 1, f, zero_quadrant(0, 1))                        // C01 ; A1 of the next K-tile
+        PP_PHASE(read_a(B, 1), stage_a(0, off_a(B, 0)), W8, 1, 1, f, zero_quadrant(1, 1))                                     // C11 ; A0 two K-tiles ahead
+        PP_PHASE((void)0, stage_w(0, off_b(B, 0)), W8, 1, 0, f, zero_quadrant(1, 0))                                          // C10 ; B0 two K-tiles ahead
         if (f) relaxed = false;
     };
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
 
     // ---- prologue: A0 B0 B1 A1 of K-tile 0 and A0 B0 of K-tile 1 in flight, the first two landed
-    stage_a(0, 0 * HALF); stage_w(0, 2 * HALF); stage_w(1, 3 * HALF); stage_a(1, 1 * HALF); advance();     // nkt >= 2: K-tile 1 exists
-    stage_a(0, BUF + 0 * HALF); stage_w(0, BUF + 2 * HALF);
+    stage_a(0, off_a(0, 0)); stage_w(0, off_b(0, 0)); stage_w(1, off_b(0, 1)); stage_a(1, off_a(0, 1)); advance();     // nkt >= 2: K-tile 1 exists
+    stage_a(0, off_a(1, 0)); stage_w(0, off_b(1, 0));
     pp_wait_vmcnt<4 * STAGE_OPS>();
     pp_barrier();
     if (!(FLAGS & 2) && wr == 1) pp_barrier();      // the second wave row runs one barrier behind the first
