@@ -92,6 +92,7 @@ def main():
     u8 = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
     mean = torch.tensor(pkg.synth.IMAGENET_MEAN); std = torch.tensor(pkg.synth.IMAGENET_STD)
     imgs = ((u8.float() - mean) / std).contiguous().cuda()
+    if os.environ.get('BENCH_RANDN'): imgs = torch.randn_like(imgs)
     probs = torch.empty((B, C), dtype=torch.float32, device="cuda")
     # Everything of a step is enqueued on ONE explicit (non-default) torch stream whose handle the engine gets: the forward, and
     # after it -- ordered by that stream -- the RCCL all-gather.  (The legacy null stream's handle is 0, which the C ABI reads as

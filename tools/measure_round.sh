@@ -7,10 +7,14 @@ out=gpurun_out/$tag; mkdir -p $out
 python bench.py --steps 30 --warmup 10 > $out/bench_bf16.json 2> $out/bench_bf16.err
 python bench.py --steps 30 --warmup 10 --dtype f16 --no-cpu-baseline > $out/bench_f16.json 2> $out/bench_f16.err
 python bench.py --steps 30 --warmup 10 --ftype q4_0 --no-cpu-baseline > $out/bench_q4_0.json 2> $out/bench_q4_0.err
+python bench.py --steps 20 --warmup 5 --model vit_large_patch16_384 --batch 128 --no-cpu-baseline > $out/bench_large384.json 2> $out/bench_large384.err
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 ( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 5 bf16 > $R/$out/prof.log 2>&1 )
 ( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $R/$out/pmc1 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 > $R/$out/pmc1.log 2>&1 )
 ( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $R/$out/pmc2 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 > $R/$out/pmc2.log 2>&1 )
 python tools/rocpd_summary.py $(find $out/prof $out/pmc1 $out/pmc2 -name "*.db" | sort) > $out/rocprofv3_summary.txt 2>&1
+python tools/hbm_traffic.py $(find $out/pmc1 -name "*.db" | head -1) $(find $out/pmc2 -name "*.db" | head -1) --commit "${COMMIT:-unknown}" --out $out/hbm_traffic.json > $out/hbm_traffic.log 2>&1
+( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/profL -o fwd -- python $R/tools/prof_forward.py vit_large_patch16_384 128 3 bf16 > $R/$out/profL.log 2>&1 )
+python tools/rocpd_summary.py $(find $out/profL -name "*.db" | sort) > $out/rocprofv3_summary_large384.txt 2>&1
 find $out -name "*.db" -size +20M -delete
 tail -c 600 $out/bench_bf16.json; echo; head -12 $out/rocprofv3_summary.txt

@@ -13,6 +13,8 @@ hp = pkg.synth.hparams_for(name)
 m = B.Model(path); ctx = B.Context(m, 0, batch, dt)
 imgs = torch.randn((batch, hp.img_size, hp.img_size, 3), device="cuda"); probs = torch.empty((batch, hp.num_classes), device="cuda")
 s = torch.cuda.current_stream().cuda_stream
+if os.environ.get("TF_STREAM"):          # an explicit torch stream, as bench.py uses
+    _st = torch.cuda.Stream(); s = _st.cuda_stream
 for _ in range(5): ctx.forward_device(imgs.data_ptr(), batch, probs.data_ptr(), 0, s)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(iters): ctx.forward_device(imgs.data_ptr(), batch, probs.data_ptr(), 0, s)
