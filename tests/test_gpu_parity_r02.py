@@ -312,9 +312,11 @@ def test_forward_large384_full_depth_vs_oracle(pkg, binding, oracle, torch_gpu):
 # ------------------------------------------------------------------------------------------------------------------
 # Attention for any token count (the reference's default hparams are patch 8 = 785 tokens, vit.h:22-28)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n_img,N,H", [(1, 785, 2), (2, 300, 1), (1, 250, 3), (3, 225, 2), (1, 1025, 1), (2, 129, 2)])
-def test_streaming_attention_any_token_count(binding, oracle, torch_gpu, n_img, N, H):
-    """Token counts the register-resident kernel is not instantiated for (or cannot hold) run the streaming kernel."""
+@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("n_img,N,H", [(1, 785, 2), (2, 300, 1), (1, 250, 3), (3, 225, 2), (1, 1025, 1), (2, 129, 2), (9, 65, 1), (2, 64, 3), (1, 1, 1)])
+def test_streaming_attention_any_token_count(binding, oracle, torch_gpu, n_img, N, H, kernel):
+    """Token counts the register-resident kernel is not instantiated for (or cannot hold) run a two-pass kernel: 2 = streaming,
+    3 = pipelined (LDS-DMA double buffering + transposed LDS reads; the automatic choice above 288 tokens)."""
     torch = torch_gpu
     D = H * 64
     rng = np.random.default_rng(n_img * 100 + N + H)
@@ -322,26 +324,48 @@ def test_streaming_attention_any_token_count(binding, oracle, torch_gpu, n_img, 
     ref = oracle.attention(qkv.astype(np.float32), n_img, N, D, H, oracle.REF)
     dq = _dev(torch, qkv)
     out = torch.zeros((n_img * N, D), dtype=torch.float16, device="cuda")
-    binding.check(binding.lib().vitx_op_attention_ex(binding.F16, 2, dq.data_ptr(), out.data_ptr(), n_img, N, D, H, None), "attention")
+    binding.check(binding.lib().vitx_op_attention_ex(binding.F16, kernel, dq.data_ptr(), out.data_ptr(), n_img, N, D, H, None), "attention")
     torch.cuda.synchronize()
     got = out.float().cpu().numpy()
     assert np.abs(got - ref).max() <= 3e-3 and np.abs(got - ref).mean() <= 3e-4
 
 
-@pytest.mark.parametrize("N", [197, 577, 50])
+@pytest.mark.parametrize("N", [197, 577, 50, 257, 32])
 def test_streaming_attention_is_bit_identical_to_single_pass(binding, torch_gpu, N):
-    """Same products, same rounding points, key tiles summed in the same order: the two kernels agree bit for bit."""
+    """Same products, same rounding points, key tiles summed in the same order: the three kernels agree bit for bit."""
     torch = torch_gpu
     n_img, H = 2, 3; D = H * 64
     g = torch.Generator(device="cuda").manual_seed(N)
     for tdt, dt in ((torch.float16, binding.F16), (torch.bfloat16, binding.BF16)):
         qkv = (torch.randn((n_img * N, 3 * D), device="cuda", generator=g) * 0.8).to(tdt)
         outs = []
-        for kernel in (1, 2):
+        for kernel in (1, 2, 3, 0):
             out = torch.zeros((n_img * N, D), dtype=tdt, device="cuda")
             binding.check(binding.lib().vitx_op_attention_ex(dt, kernel, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
             torch.cuda.synchronize(); outs.append(out)
-        assert torch.equal(outs[0], outs[1])
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o)
+
+
+@pytest.mark.parametrize("N", [577, 70, 197])
+def test_pipelined_attention_never_reads_past_the_tensor(binding, torch_gpu, N):
+    """The pipelined kernel streams whole 64-key chunks: keys past N of the LAST image would lie behind the qkv tensor.  Its buffer
+    descriptor ends at the tensor, so those loads return 0 -- NaNs planted right behind the tensor (and in the output's slack) must
+    not reach the result, and the result must equal the one computed from an unpoisoned copy."""
+    torch = torch_gpu
+    n_img, H = 3, 2; D = H * 64
+    g = torch.Generator(device="cuda").manual_seed(7 * N)
+    rows = n_img * N
+    big = torch.full((rows + 128, 3 * D), float("nan"), device="cuda", dtype=torch.bfloat16)
+    big[:rows] = (torch.randn((rows, 3 * D), device="cuda", generator=g) * 0.8).to(torch.bfloat16)
+    clean = big[:rows].clone()
+    outs = []
+    for src in (big, clean):
+        out = torch.zeros((rows, D), dtype=torch.bfloat16, device="cuda")
+        binding.check(binding.lib().vitx_op_attention_ex(binding.BF16, 3, src.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
+        torch.cuda.synchronize(); outs.append(out)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_forward_patch8_785_tokens_vs_oracle(pkg, binding, oracle, torch_gpu):

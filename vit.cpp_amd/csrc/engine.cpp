@@ -520,12 +520,17 @@ int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *b
     return op_gemm_impl(dtype, epi, 0, a, w, bias, out, nullptr, M, M, N, round_up(N, gemm_tile_n()), K, 0, stream);   // W and bias hold N rounded up to 128 rows
 }
 int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
-    if (!qkv || !out || n_img <= 0 || kernel < 0 || kernel > 2) return VITX_ERR_ARG;
+    if (!qkv || !out || n_img <= 0 || kernel < 0 || (kernel & 15) > 3) return VITX_ERR_ARG;
     const Tuning *t0 = tuning_for_device(-1);
     if (!t0) { set_error("vitx_op_attention: kernel bring-up failed"); return VITX_ERR_HIP; }
     Tuning t = *t0;
-    if (kernel == 2) t.attn_waves = 0;                       // streaming kernel
-    else if (kernel == 1) { if (!attention_single_pass_supports(N)) { set_error("vitx_op_attention: no single-pass instantiation for %d tokens", N); return VITX_ERR_UNSUPPORTED; } if (t.attn_waves == 0) t.attn_waves = 4; }
+    t.attn_flags = kernel >> 4; kernel &= 15;                // bits 4+: ablation build of the pipelined kernel (tools/attn_bench.py only)
+    if (kernel == 3) t.attn_waves = -1;                      // pipelined two-pass kernel
+    else if (kernel == 2) t.attn_waves = 0;                  // streaming kernel
+    else if (kernel == 1) {                                  // single-pass kernel, also where the automatic choice prefers the pipelined one
+        if (!attention_single_pass_supports(N)) { set_error("vitx_op_attention: no single-pass instantiation for %d tokens", N); return VITX_ERR_UNSUPPORTED; }
+        t.attn_waves = -2;
+    }
     hipError_t e = launch_attention(t, dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_attention: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
     return VITX_OK;

@@ -40,7 +40,9 @@ struct Tuning {
     int gemm_stream = 1;     // VITX_GEMM_STREAM=0: one workgroup per tile (445) instead of the persistent 945 when the ring kernels run
     int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
     int gemm_split = 0;      // VITX_GEMM_SPLIT=1: tail rows of a partial round re-tiled 128x256 in a second launch (r01 default; off since the persistent kernel)
+    int gemm_balance = 1;    // VITX_GEMM_BALANCE=0: launch one workgroup per CU even when the last round of tiles is partial
     int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
+    int attn_flags = 0;      // ablation build of the pipelined attention kernel (tools/attn_bench.py); 0 = product
     int attn_waves = 4;      // VITX_ATTN_WAVES
 };
 // Looks the device up (hipGetDevice when device < 0), reads the environment once per process, and on first use of a device

@@ -168,15 +168,30 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream, 
 //   * anything the ring kernels cannot tile: the v1 128x128 kernel.
 static int wide_ring_cfg(const Tuning &t, const GemmArgs &a) { return (t.gemm_stream && gemm_ring_supports(a, 945)) ? 945 : 445; }
 
+// Persistent grid of the ping-pong kernel.  Tiles are dealt round-robin, so with one workgroup per CU a partial last round
+// (e.g. 339 tiles = 256 + 83) leaves most of the chip idle while the first round ran at the power-capped clock.  Balanced:
+// rounds = ceil(tiles / CUs), grid = ceil(tiles / rounds) rounded up to the 8 XCDs -- every workgroup walks the same number
+// of tiles, fewer CUs are lit at a higher clock (the GEMM is energy-bound: half the CUs deliver 76 % of the throughput),
+// and the CUs left free take the other sub-batch's kernels.
+static int pp_grid(const Tuning &t, const GemmArgs &a) {
+    int cap = t.n_cu & ~7;
+    if (cap <= 0) cap = 256;
+    const long ntiles = (long)(a.M / 256) * (a.N_pad / 256);
+    if (!t.gemm_balance || ntiles <= cap) return cap;
+    const long rounds = (ntiles + cap - 1) / cap;
+    const long g = ((ntiles + rounds - 1) / rounds + 7) & ~7L;
+    return (int)(g < cap ? g : cap);
+}
+
 static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
-    if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, t.n_cu, stream);
+    if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream);
     return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(t, a), stream);
 }
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
     int cfg = t.gemm_cfg;
-    if (cfg == 1) return launch_gemm_pp(dtype, epi, a, t.n_cu, stream);
+    if (cfg == 1) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream);
     if (cfg > 1) return gemm_ring_supports(a, cfg) ? launch_gemm_ring(t, dtype, epi, a, cfg, stream) : hipErrorInvalidValue;
     if (cfg < 0) {
         const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
@@ -680,18 +695,258 @@ static hipError_t launch_attention_stream(const void *qkv, void *out, int n_img,
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined two-pass attention (vit.cpp:826-866), any token count.  Same arithmetic as the two kernels above (same products,
+// rounding points and summation order: bit-identical results), laid out for latency hiding instead of register residency:
+//   * a workgroup = 4 waves = 4 query tiles of one (image, head); the query blocks of one (image, head) share an XCD (L2 hits
+//     on the re-streamed K/V);
+//   * keys stream through LDS in chunks of 64 (8 KiB K + 8 KiB V), double buffered, by LDS-DMA (buffer_load ... lds): no
+//     staging registers and no VALU work -- the softmax's exp/convert instructions are what bounds this kernel.  K lands in the
+//     swizzled row image (swizzle applied on the source side), V lands ROW-major and the V^T fragments of O^T = V^T P^T come
+//     out of ds_read_b64_tr_b16 (a 16-lane group reads a [4 keys][16 dims] block and receives it transposed: lane i gets dim
+//     i of keys 0..3, which is the k-slot order of the P registers -- tools/tr_probe.hip prints the mapping);
+//   * 32 KiB of LDS and <= 128 VGPRs: four workgroups = 16 waves per CU, so the MFMA work of one wave runs under the VALU work
+//     of the others (the single-pass kernel holds every score in registers: one wave per SIMD at 577 tokens).
+// Pass 1 streams K for the row maxima, pass 2 streams K and V.  Keys past N inside the last chunk read the next image's rows
+// (finite values; their scores are masked to -inf and their probabilities are exactly 0) or, past the end of the tensor, the
+// zeros a buffer load returns out of range.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int FLAGS>      // FLAGS: ablation builds of tools/attn_bench.py (1 no re-staging, 2 no barriers, 4 no exp/convert, 8 no PV, 16 no pass 1); 0 = product
+__global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int qblocks, int items, int n_img) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CK = 64, KBYTES = CK * 128, VBYTES = CK * 128, BUF = KBYTES + VBYTES;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blockIdx -> (item, query block): blocks whose index is equal mod 8 run on one XCD; an item's query blocks are consecutive there
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int item = (jb / qblocks) * 8 + xcd, qb = jb % qblocks;
+    if (item >= items) return;
+    const int b = item / H, h = item % H;
+    const T *base = qkv + (size_t)b * N * 3 * D + h * 64;
+    typedef typename Elem<T>::v8 v8;
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const int nch = (N + CK - 1) / CK;
+    const int row_bytes = 3 * D * 2;
+
+    const int qrow = (qb * 4 + wave) * 32 + l31;
+    const bool qvalid = qrow < N;
+    const bool wave_live = (qb * 4 + wave) * 32 < N;          // a wave past the last query tile only takes part in the barriers
+    v8 qf[4];
+    {
+        const int qr = min(qrow, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qr * 3 * D + ks * 16 + hh * 8);
+    }
+
+    // ---- LDS-DMA: physical 16-B piece p = it*256 + tid of a chunk image <-> (key row, 16-B slot) of the K / V column block
+    const unsigned remaining = (unsigned)min((size_t)0xf0000000u, ((size_t)(n_img - b) * N * 3 * D - h * 64) * 2);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)remaining, 0x00020000);
+    int koff[2], voff[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int p = it * 256 + tid;
+        int rr, sl; swz_inv(p, rr, sl);
+        koff[it] = rr * row_bytes + D * 2 + sl * 16;
+        const int vr = p >> 3, vs = (p & 7) ^ (((vr >> 1) & 1) << 2);          // V image: 16-B slot ^ 4 on rows 2, 3 (mod 4)
+        voff[it] = vr * row_bytes + 2 * D * 2 + vs * 16;
+    }
+    auto stage = [&](char *buf, int key0, bool with_v) {
+        char *dst = buf + wave * 1024;
+        const int so = key0 * row_bytes;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + it * 4096), 16, koff[it], so, 0, 0);
+        if (with_v) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + KBYTES + it * 4096), 16, voff[it], so, 0, 0);
+        }
+    };
+    // V^T fragment addresses: lane of a 16-lane group g = (lane >> 4) & 1 (dims 16g..16g+15 of the 32-dim tile) supplies the
+    // address of key row (lane & 15) >> 2 (+ 4 hh), dims 4 (lane & 3)..+3; the tile's dt bit and the row's swizzle bit share bit 6
+    int vrd[2];
+    {
+        const int r = 4 * hh + ((lane & 15) >> 2), rb = (r >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vrd[dt] = KBYTES + r * 128 + ((dt ^ rb) << 6) + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    }
+    // K fragment addresses inside a chunk image: tile kt adds kt * 4096 (the swizzle term depends on l31 only)
+    int krd[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) krd[ks] = swz_byte(l31, ks * 2 + hh);
+    auto qk_tile = [&](const char *cur, int kt, f32x16 &s) {             // S^T tile = K tile . Q^T (4 MFMAs)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = Elem<T>::mfma(*(const v8 *)(cur + krd[ks] + kt * 4096), qf[ks], s);
+    };
+    auto mask_tile = [&](int kt, int key0, f32x16 &s) {                   // keys >= N of the last chunk: -inf
+        if (key0 + kt * 32 + 32 > N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) s[r] = -INFINITY;
+        }
+    };
+    auto max_tile = [&](const f32x16 &s, float &m) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(s[r], s[r + 1]), m);        // v_max3_f32
+    };
+
+    stage(smem, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
+    __syncthreads();
+
+    // ---- pass 1: global row maximum of the raw scores.  Chunk c is computed out of buffer c & 1 while the DMA of chunk c + 1
+    // fills the other one; after the last chunk comes chunk 0 of pass 2 (with V).
+    float mxs = -INFINITY;
+    for (int c = 0; c < nch; ++c) {
+        const int key0 = c * CK;
+        const char *cur = smem + (c & 1) * BUF;
+        char *nxt = smem + ((c + 1) & 1) * BUF;
+        const bool last = c + 1 == nch;
+        if (!(FLAGS & 1) || last) stage(nxt, last ? 0 : key0 + CK, last);
+        if (wave_live && !(FLAGS & 16)) {
+            const int nt = min(2, (N - key0 + 31) / 32);
+            for (int kt = 0; kt < nt; ++kt) {
+                f32x16 s; qk_tile(cur, kt, s);
+                if (last) mask_tile(kt, key0, s);
+                max_tile(s, mxs);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        if (!(FLAGS & 2) || last) __syncthreads();
+    }
+    mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+
+    // ---- pass 2: exponentials against the global maximum, row sum of the ROUNDED values, O^T = V^T P^T
+    float sum = 0.0f;
+    const float nmx = -0.125f * mxs;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+    auto exp_tile = [&](const f32x16 &s, v8 (&p)[2]) {      // e = round(exp(round(s/8 - max/8))) per ggml_soft_max, row sum of the rounded values
+        if constexpr (FLAGS & 4) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const typename Pair<T>::v2 eh = round_pair<T>(s[r], s[r + 1]);
+                p[r >> 3][r & 7] = eh[0]; p[r >> 3][(r & 7) + 1] = eh[1];
+            }
+            sum += s[0];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[r], 0.125f, nmx), __builtin_fmaf(s[r + 1], 0.125f, nmx));
+                const f32x2 t = f32x2{(float)dh[0], (float)dh[1]} * f32x2{1.44269504f, 1.44269504f};
+                const typename Pair<T>::v2 eh = round_pair<T>(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
+                sum = Pair<T>::sum2(eh, sum);
+                p[r >> 3][r & 7] = eh[0]; p[r >> 3][(r & 7) + 1] = eh[1];
+            }
+        }
+    };
+    // The V^T fragments are read with inline asm: behind the builtin hipcc puts `s_waitcnt vmcnt(0)` in front of every transposed
+    // read (it cannot tell the read from the in-flight LDS-DMA of the NEXT chunk), which exposed the whole DMA latency per chunk.
+    // "=v" results + one wait statement that owns them keeps the MFMAs below the wait.
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char *)smem);
+    auto pv_tile = [&](const char *cur, int kt, const v8 (&p)[2]) {      // O^T += V^T tile . P^T tile (4 MFMAs, 8 transposed reads)
+        if constexpr (FLAGS & 8) { o[0][0] += (float)p[0][0] + (float)p[1][0]; } else {
+            const unsigned cb = lds0 + (unsigned)(cur - smem) + kt * 32 * 128;
+            s4 f[2][2][2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const unsigned va = cb + vrd[dt];
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt][0][0]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f[dt][0][1]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[dt][1][0]) : "v"(va));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(f[dt][1][1]) : "v"(va));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]),
+                                                  "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+            typedef short s8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const s8 both = __builtin_shufflevector(f[dt][half][0], f[dt][half][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = Elem<T>::mfma(__builtin_bit_cast(v8, both), p[half], o[dt]);
+                }
+        }
+    };
+    for (int c = 0; c < nch; ++c) {
+        const int key0 = c * CK;
+        // pass 1's last stage filled buffer nch & 1: pass 2's chunk c lives in buffer (nch + c) & 1
+        const char *cur = smem + ((nch + c) & 1) * BUF;
+        char *nxt = smem + ((nch + c + 1) & 1) * BUF;
+        const bool last = c + 1 == nch;
+        if (!last && !(FLAGS & 1)) stage(nxt, key0 + CK, true);
+        if (wave_live) {
+            const int nt = min(2, (N - key0 + 31) / 32);
+            for (int kt = 0; kt < nt; ++kt) {
+                f32x16 s; v8 p[2];
+                qk_tile(cur, kt, s);
+                if (last) mask_tile(kt, key0, s);
+                exp_tile(s, p); pv_tile(cur, kt, p);
+            }
+        }
+        if (!last) { __builtin_amdgcn_s_waitcnt(0x0f70); if (!(FLAGS & 2)) __syncthreads(); }
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    if (qvalid) {
+        T *orow = out + ((size_t)b * N + qrow) * D + h * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                typename Elem<T>::v4 w4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w4[e] = (T)(o[dt][r4 * 4 + e] * inv);
+                *(typename Elem<T>::v4 *)(orow + dt * 32 + r4 * 8 + hh * 4) = w4;
+            }
+    }
+}
+template <typename T, int FLAGS>
+static hipError_t launch_attention_flow_inst(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+    constexpr int lds = 2 * (64 * 128 + 64 * 128);        // two (8 KiB K + 8 KiB V) chunk buffers
+    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_flow_kernel<T, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
+    const int qblocks = ((N + 31) / 32 + 3) / 4, items = n_img * H;
+    const int grid = ((items + 7) / 8) * 8 * qblocks;
+    hipLaunchKernelGGL((attention_flow_kernel<T, FLAGS>), dim3(grid), dim3(256), lds, stream, (const T *)qkv, (T *)out, N, D, H, qblocks, items, n_img);
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream, int flags = 0) {
+    switch (flags) {
+    case 0: return launch_attention_flow_inst<T, 0>(qkv, out, n_img, N, D, H, stream);
+    case 1: return launch_attention_flow_inst<T, 1>(qkv, out, n_img, N, D, H, stream);
+    case 2: return launch_attention_flow_inst<T, 2>(qkv, out, n_img, N, D, H, stream);
+    case 3: return launch_attention_flow_inst<T, 3>(qkv, out, n_img, N, D, H, stream);
+    case 4: return launch_attention_flow_inst<T, 4>(qkv, out, n_img, N, D, H, stream);
+    case 8: return launch_attention_flow_inst<T, 8>(qkv, out, n_img, N, D, H, stream);
+    case 12: return launch_attention_flow_inst<T, 12>(qkv, out, n_img, N, D, H, stream);
+    case 16: return launch_attention_flow_inst<T, 16>(qkv, out, n_img, N, D, H, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 static const int kAttnNkt[] = {1, 2, 3, 4, 5, 6, 7, 9, 19};      // instantiated key-tile counts (tokens = 32 * nkt, rounded up)
 bool attention_single_pass_supports(int N) {
     const int nkt = (N + 31) / 32;
     for (int k : kAttnNkt) if (k == nkt) return true;
     return false;
 }
-bool attention_supports(int N, int D, int H) { return D == H * 64 && N > 0; }      // any token count: single-pass kernel where instantiated, else the streaming kernel
+bool attention_supports(int N, int D, int H) { return D == H * 64 && N > 0; }      // any token count
+// Kernel choice (measured, 128 x 12 heads bf16: 197 tokens 52 vs 55 us, 257 tokens 77 vs 92 us single-pass vs pipelined;
+// 64 x 16 heads x 577 tokens 282 vs 241 us; 785 tokens: streaming 66 vs pipelined 44 us -- profiles/r02_attention.txt):
+//   single-pass (all scores in registers) up to 288 tokens where instantiated, the pipelined two-pass kernel for everything else.
+// VITX_ATTN_WAVES: 0 forces the streaming kernel, -1 the pipelined one, 7 the 7-wave single-pass build for 197 tokens.
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
-    if (!attention_single_pass_supports(N) || t.attn_waves == 0)       // VITX_ATTN_WAVES=0 forces the streaming kernel (tests)
+    if (t.attn_waves == 0)
         return dtype == DT_F16 ? launch_attention_stream<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_stream<__bf16>(qkv, out, n_img, N, D, H, stream);
-    return dtype == DT_F16 ? launch_attention_t<_Float16>(t.attn_waves, qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(t.attn_waves, qkv, out, n_img, N, D, H, stream);
+    const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_waves == -2);      // -2: vitx_op_attention_ex(kernel 1)
+    if (t.attn_waves == -1 || !single)
+        return dtype == DT_F16 ? launch_attention_flow<_Float16>(qkv, out, n_img, N, D, H, stream, t.attn_flags) : launch_attention_flow<__bf16>(qkv, out, n_img, N, D, H, stream, t.attn_flags);
+    const int waves = t.attn_waves > 0 ? t.attn_waves : 4;
+    return dtype == DT_F16 ? launch_attention_t<_Float16>(waves, qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(waves, qkv, out, n_img, N, D, H, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -707,6 +962,7 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
         if ((e = (dt == DT_F16 ? launch_attention_stream<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_stream<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
+        if ((e = (dt == DT_F16 ? launch_attention_flow<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_flow<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
         for (int nkt : kAttnNkt) {
             for (int w : {4, 7}) {
                 if (w == 7 && nkt != 7) continue;
@@ -736,6 +992,7 @@ const Tuning *tuning_for_device(int device) {
     t->gemm_stream = env_int("VITX_GEMM_STREAM", 1);
     t->gemm_skinny = getenv("VITX_GEMM_NOSKINNY") == nullptr;
     t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);      // r02: with the persistent ping-pong kernel the two-launch tail split costs 5 % of the step (profiles/r02_forward_sweeps.txt)
+    t->gemm_balance = env_int("VITX_GEMM_BALANCE", 1);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
     const hipError_t e = prepare_device_kernels(*t);
