@@ -177,6 +177,12 @@ def main():
             "config": {"workload": f"{args.model} {args.dtype} ({args.ftype} weight file), batch={B} per GPU, {S}x{S}x3 f32 HWC inputs in HBM, random-init weights in the reference's file format",
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, replicated weights, 1 all-gather of probs/step)" if world > 1 else "single GPU"},
             "gflop_per_image": round(gflop, 4), "weights": args.ftype,
+            "weight_bytes_hbm": ctx.weight_bytes(),
+            "weight_path": ("16-bit operand matrices resident in HBM" if args.ftype == "f16" else
+                            ("expanded once on the host at upload (VITX_QUANT_HOST=1)" if os.environ.get("VITX_QUANT_HOST") else
+                             f"{args.ftype} blocks resident in HBM; each layer's matrices expanded on the device just in time (dequant_kernel, quant.hip) into a "
+                             "per-stream scratch, then the same wide-tile MFMA kernels as the f16 file (q4_0 GEMMs of <= VITX_Q4_FUSED_ROWS rows expand "
+                             "inside the GEMM instead)")),
             "mfma_roofline_frac_whole_forward": round(value / world * gflop / 1e3 / PEAK_TFLOPS, 4),
         }
         # roofline of the dominant kernel: algorithmic flops / HIP-event time on the launch stream

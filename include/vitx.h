@@ -176,6 +176,20 @@ int vitx_op_gemm(int dtype, int epi, const void *d_a, const void *d_w, const voi
  * VITX_ERR_UNSUPPORTED when the chosen kernel cannot tile the shape. */
 int vitx_op_gemm_ex(int dtype, int epi, int kernel, const void *d_a, const void *d_w, const void *d_bias, void *d_out, const void *d_pos,
                     int M, int M_real, int N, int K, int tpi, void *stream);
+/* Block-quantised weights on the device (reference: ggml keeps q4_0 ... q8_0 tensors in block form through compute,
+ * vit.cpp:384-414, 645-678).  A context built from a quantised file keeps the blocks in HBM (vitx_ctx_weight_bytes reports the
+ * footprint; env VITX_QUANT_HOST=1 expands once on the host instead) and expands them on the device:
+ *   vitx_op_dequant : out[n_pad][K] (dtype) = expansion of N rows of K/32 blocks of type `qtype` (2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1,
+ *                     8 q8_0) laid out as in the file -- except q4_0: d_blocks = nibble plane [N][K/32][16 bytes],
+ *                     d_scales = f16 block scales [N][K/32] (d_scales is ignored for the other types); rows N..n_pad are zeros.
+ *                     Values are the reference's dequantize_row_* results rounded once (nearest-even) to dtype.
+ *   vitx_op_gemm_q4 : C = A[M][K] . dequant(W)^T with the q4_0 blocks expanded in the GEMM's LDS-fill path; d_qs / d_scales as
+ *                     above but with N rounded up to 128 rows (zero scales in the pad rows), epi 0..3 as vitx_op_gemm. */
+int vitx_op_dequant(int dtype, int qtype, const void *d_blocks, const void *d_scales, void *d_out, int N, int n_pad, int K, void *stream);
+int vitx_op_gemm_q4(int dtype, int epi, const void *d_a, const void *d_qs, const void *d_scales, const void *d_bias, void *d_out,
+                    int M, int M_real, int N, int K, void *stream);
+/* Device bytes held by the context's weight matrices (blocks for quantised tensors, 16-bit operands otherwise). */
+size_t vitx_ctx_weight_bytes(const vitx_ctx *c);
 /* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
 int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* kernel 0 = automatic, 1 = single-pass kernel (N <= 224, 257-288 or 577-608 tokens only), 2 = streaming two-pass kernel (any N),

@@ -8,7 +8,8 @@ batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 name = sys.argv[2] if len(sys.argv) > 2 else "vit_base_patch16_224"
 dt = B.F16 if (len(sys.argv) > 3 and sys.argv[3] == "f16") else B.BF16
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 30
-path = pkg.synth.cached_synthetic(name, head_scale=8.0)
+ftype = {"f16": 1, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}[os.environ.get("TF_FTYPE", "f16")]      # weight file type
+path = pkg.synth.cached_synthetic(name, ftype=ftype, head_scale=8.0)
 hp = pkg.synth.hparams_for(name)
 m = B.Model(path); ctx = B.Context(m, 0, batch, dt)
 imgs = torch.randn((batch, hp.img_size, hp.img_size, 3), device="cuda"); probs = torch.empty((batch, hp.num_classes), device="cuda")
@@ -23,5 +24,5 @@ torch.cuda.synchronize(); dt_ = (time.perf_counter() - t0) / iters
 lat = []
 for _ in range(20):
     t1 = time.perf_counter(); ctx.forward_device(imgs.data_ptr(), batch, probs.data_ptr(), 0, s); torch.cuda.synchronize(); lat.append(time.perf_counter() - t1)
-print(f"{name} batch {batch}: {dt_*1e3:.3f} ms/step pipelined ({batch/dt_:.0f} img/s); isolated call median {sorted(lat)[10]*1e3:.3f} ms")
+print(f"{name} {os.environ.get('TF_FTYPE', 'f16')}-file batch {batch}: {dt_*1e3:.3f} ms/step pipelined ({batch/dt_:.0f} img/s); isolated call median {sorted(lat)[10]*1e3:.3f} ms")
 ctx.close(); m.close()

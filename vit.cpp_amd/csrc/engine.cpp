@@ -32,14 +32,23 @@ namespace {
 
 enum ProfClass {
     PC_PATCHIFY = 0, PC_GEMM_PATCH, PC_CLS, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_GEMM_PROJ, PC_GEMM_FC1, PC_GEMM_FC2,
-    PC_GEMM_HEAD, PC_SOFTMAX, PC_COUNT
+    PC_GEMM_HEAD, PC_SOFTMAX, PC_DEQUANT, PC_COUNT
 };
 const char *kProfNames[PC_COUNT] = {"patchify", "gemm_patch_embed", "cls_rows", "layernorm", "gemm_qkv_bias", "attention", "gemm_proj_resid",
-                                    "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_head", "softmax"};
+                                    "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_head", "softmax", "dequant_weights"};
 
+// A weight matrix kept in the file's block form on the device (quant.hip): `blocks` = N rows of K/32 blocks in the file's byte
+// layout -- except q4_0, which is split into a nibble plane (`blocks`, 16 B per block, rows padded to n_pad) and an f16 scale
+// plane (`scales`) so both the dequant kernel and the fused small-batch GEMM read aligned 16-byte pieces.  Same bits, same size.
+struct QuantW {
+    void *blocks = nullptr; uint16_t *scales = nullptr;
+    int type = 0, N = 0, K = 0, n_pad = 0;
+};
+enum { W_QKV = 0, W_PROJ, W_FC1, W_FC2, W_PER_LAYER };
 struct LayerW {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
-    void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    void *qkv_w, *proj_w, *fc1_w, *fc2_w;      // expanded operand-type matrices; nullptr where the blocks stay quantised (q[])
+    QuantW q[W_PER_LAYER];
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -61,7 +70,12 @@ struct vitx_ctx {
     // weights
     float *cls = nullptr, *pos = nullptr, *pe_b = nullptr, *norm_w = nullptr, *norm_b = nullptr, *head_b = nullptr;
     void *pe_w = nullptr, *head_w = nullptr;
+    QuantW head_q;
     std::vector<LayerW> layers;
+    // quantised files: VITX_QUANT_HOST=1 restores the r01 behaviour (expand once on the host at upload, 16 bits per weight in HBM)
+    bool quant_on_device = true;
+    int q4_fused_rows = 4096;            // q4_0 GEMMs with at most this many rows expand the blocks inside the GEMM (VITX_Q4_FUSED_ROWS)
+    size_t weight_bytes = 0;             // device bytes held by weight matrices (vitx_ctx_weight_bytes)
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
     // (measured +10 % images/s at batch 256, tools/two_stream_probe.py).  Sub-batches are independent images.
@@ -72,6 +86,8 @@ struct vitx_ctx {
         void *QKV = nullptr;         // [Mpad][3D]
         void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
         void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
+        void *Wq[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};   // just-in-time expansion of the current layer's quantised matrices
+        void *Wq_head = nullptr;
         float *logits = nullptr;     // [Bpad][C_pad]
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
@@ -146,6 +162,42 @@ int upload_matrix(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad,
     int rc = c->dmalloc(out, h.size() * 2, false);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(*out, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    c->weight_bytes += h.size() * 2;
+    return VITX_OK;
+}
+int upload_quant(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad, QuantW *q);
+// A 2-D "*weight" tensor: block types stay quantised on the device (q), everything else is uploaded expanded (dense).
+int upload_weight(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad, void **dense, QuantW *q) {
+    *dense = nullptr;
+    if (c->quant_on_device) { int rc = upload_quant(c, t, Nrows, K, n_pad, q); if (rc) return rc; }
+    if (q->blocks) return VITX_OK;
+    return upload_matrix(c, t, Nrows, K, n_pad, K, dense);
+}
+
+// Quantised [N][K] matrix -> device, still in block form.  Returns VITX_OK with q->blocks == nullptr when the tensor is not a
+// block type (the caller then uploads the expanded matrix).
+int upload_quant(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad, QuantW *q) {
+    const int bb = type_block_bytes(t->type);
+    if (t->type == T_F32 || t->type == T_F16 || !bb || K % 32) return VITX_OK;
+    const size_t nbk = (size_t)K / 32;
+    q->type = t->type; q->N = Nrows; q->K = K; q->n_pad = n_pad;
+    int rc;
+    if (t->type == T_Q4_0) {        // split planes, rows padded (zero scales -> the pad rows expand to zeros)
+        std::vector<uint8_t> qs((size_t)n_pad * nbk * 16, 0);
+        std::vector<uint16_t> ds((size_t)n_pad * nbk, 0);
+        const uint8_t *src = t->raw.data();
+        for (size_t b = 0; b < (size_t)Nrows * nbk; ++b) { memcpy(&ds[b], src + b * 18, 2); memcpy(&qs[b * 16], src + b * 18 + 2, 16); }
+        if ((rc = c->dmalloc(&q->blocks, qs.size(), false))) return rc;
+        if ((rc = c->dmalloc((void **)&q->scales, ds.size() * 2, false))) return rc;
+        HIP_TRY(hipMemcpy(q->blocks, qs.data(), qs.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(q->scales, ds.data(), ds.size() * 2, hipMemcpyHostToDevice));
+        c->weight_bytes += qs.size() + ds.size() * 2;
+    } else {
+        const size_t bytes = (size_t)Nrows * nbk * bb;
+        if ((rc = c->dmalloc(&q->blocks, bytes, false))) return rc;
+        HIP_TRY(hipMemcpy(q->blocks, t->raw.data(), bytes, hipMemcpyHostToDevice));
+        c->weight_bytes += bytes;
+    }
     return VITX_OK;
 }
 
@@ -160,14 +212,20 @@ struct ProfScope {
     ~ProfScope() { if (on) (void)hipEventRecord(c->recs[idx].b, s); }
 };
 
+// `fused` != nullptr: W is that q4_0 matrix and the GEMM expands the blocks in its own LDS-fill path (small batches).
 int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
-         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes) {
+         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr) {
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
     a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
-    double bytes = (double)M_real * K * 2 + (double)N * K * 2 + (double)M_real * N * out_elem_bytes;
+    double bytes = (double)M_real * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
     ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
+    if (fused) {
+        a.W = fused->blocks; a.Wscale = fused->scales;
+        HIP_TRY(launch_gemm_q4(c->dtype, epi, a, st));
+        return VITX_OK;
+    }
     HIP_TRY(launch_gemm(tune, c->dtype, epi, a, st));
     return VITX_OK;
 }
@@ -206,6 +264,8 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         for (const char *p = e; i < 3 && *p; ++i) { c->split_override[i] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
     }
     c->slices_serial = getenv("VITX_SLICES_SERIAL") != nullptr;
+    c->quant_on_device = getenv("VITX_QUANT_HOST") == nullptr;
+    if (const char *e = getenv("VITX_Q4_FUSED_ROWS")) c->q4_fused_rows = atoi(e);
     if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);     // for rocprofv3 runs that should match the profiled steps
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
@@ -228,15 +288,15 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         if ((rc = upload_f32(c.get(), T(p + "attn.proj.bias"), &w.proj_b, round_up(D, tn)))) return rc;
         if ((rc = upload_f32(c.get(), T(p + "mlp.fc1.bias"), &w.fc1_b, round_up(4 * D, tn)))) return rc;
         if ((rc = upload_f32(c.get(), T(p + "mlp.fc2.bias"), &w.fc2_b, round_up(D, tn)))) return rc;
-        if ((rc = upload_matrix(c.get(), T(p + "attn.qkv.weight"), 3 * D, D, round_up(3 * D, tn), D, &w.qkv_w))) return rc;
-        if ((rc = upload_matrix(c.get(), T(p + "attn.proj.weight"), D, D, round_up(D, tn), D, &w.proj_w))) return rc;
-        if ((rc = upload_matrix(c.get(), T(p + "mlp.fc1.weight"), 4 * D, D, round_up(4 * D, tn), D, &w.fc1_w))) return rc;
-        if ((rc = upload_matrix(c.get(), T(p + "mlp.fc2.weight"), D, 4 * D, round_up(D, tn), 4 * D, &w.fc2_w))) return rc;
+        if ((rc = upload_weight(c.get(), T(p + "attn.qkv.weight"), 3 * D, D, round_up(3 * D, tn), &w.qkv_w, &w.q[W_QKV]))) return rc;
+        if ((rc = upload_weight(c.get(), T(p + "attn.proj.weight"), D, D, round_up(D, tn), &w.proj_w, &w.q[W_PROJ]))) return rc;
+        if ((rc = upload_weight(c.get(), T(p + "mlp.fc1.weight"), 4 * D, D, round_up(4 * D, tn), &w.fc1_w, &w.q[W_FC1]))) return rc;
+        if ((rc = upload_weight(c.get(), T(p + "mlp.fc2.weight"), D, 4 * D, round_up(D, tn), &w.fc2_w, &w.q[W_FC2]))) return rc;
     }
     if ((rc = upload_f32(c.get(), T("norm.weight"), &c->norm_w))) return rc;
     if ((rc = upload_f32(c.get(), T("norm.bias"), &c->norm_b))) return rc;
     if ((rc = upload_f32(c.get(), T("head.bias"), &c->head_b, c->C_pad))) return rc;
-    if ((rc = upload_matrix(c.get(), T("head.weight"), c->C, D, c->C_pad, D, &c->head_w))) return rc;
+    if ((rc = upload_weight(c.get(), T("head.weight"), c->C, D, c->C_pad, &c->head_w, &c->head_q))) return rc;
 
     // sub-batch slices (VITX_STREAMS overrides; 1 = single stream).  Small contexts stay single-slice.
     int ns = 2;
@@ -257,6 +317,13 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
         if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
+        // expansion scratch for quantised matrices: one buffer per matrix kind, shared by all layers (the largest layer decides)
+        for (int k = 0; k < W_PER_LAYER; ++k) {
+            size_t need = 0;
+            for (const LayerW &w : c->layers) if (w.q[k].blocks) need = std::max(need, (size_t)w.q[k].n_pad * w.q[k].K * 2);
+            if (need && (rc = c->dmalloc(&sl.Wq[k], need, false))) return rc;
+        }
+        if (c->head_q.blocks && (rc = c->dmalloc(&sl.Wq_head, (size_t)c->head_q.n_pad * c->head_q.K * 2, false))) return rc;
         sl.tune = *c->tune;
         if (ns > 1) {
             // The runtime multiplexes all streams of one priority onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by
@@ -313,27 +380,58 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         HIP_TRY(launch_cls_rows(c->cls, c->pos, sl.X, n, N, D, st));
     }
     if (!c->trace_ids.empty() && (rc = trace(0))) return rc;
+    // Quantised matrices (block form in HBM): a q4_0 GEMM with few rows expands the blocks in its own LDS-fill path; everything else
+    // is expanded just in time, one launch per layer, into the slice's scratch and then streamed by the wide-tile kernels.
+    auto fused_ok = [&](const QuantW &q, int rows) { return q.blocks && q.type == T_Q4_0 && rows <= c->q4_fused_rows && rows % 128 == 0 && q.n_pad % 128 == 0 && q.K % 64 == 0; };
+    auto expand = [&](const QuantW *const *qs, void *const *dst, int count) -> int {
+        bool done[W_PER_LAYER] = {false, false, false, false};
+        for (int k = 0; k < count; ++k) {
+            if (done[k] || !qs[k]) continue;
+            DequantJob jobs[4]; int nj = 0; double bytes = 0;
+            for (int m = k; m < count; ++m) {
+                if (done[m] || !qs[m] || qs[m]->type != qs[k]->type) continue;
+                jobs[nj++] = DequantJob{qs[m]->blocks, qs[m]->scales, dst[m], qs[m]->N, qs[m]->n_pad, qs[m]->K / 32};
+                bytes += (double)qs[m]->N * qs[m]->K / 32 * type_block_bytes(qs[m]->type) + (double)qs[m]->n_pad * qs[m]->K * eb;
+                done[m] = true;
+            }
+            ProfScope ps(c, st, PC_DEQUANT, 0, bytes);
+            HIP_TRY(launch_dequant(dt, qs[k]->type, jobs, nj, st));
+        }
+        return VITX_OK;
+    };
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
+        const void *Wl[W_PER_LAYER] = {w.qkv_w, w.proj_w, w.fc1_w, w.fc2_w};
+        const QuantW *Fl[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};      // matrices the fused kernel takes
+        {
+            const QuantW *todo[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};
+            bool any = false;
+            for (int k = 0; k < W_PER_LAYER; ++k) {
+                if (!w.q[k].blocks) continue;
+                if (fused_ok(w.q[k], M)) Fl[k] = &w.q[k];
+                else { todo[k] = &w.q[k]; Wl[k] = sl.Wq[k]; any = true; }
+            }
+            if (any && (rc = expand(todo, sl.Wq, W_PER_LAYER))) return rc;
+        }
         {   // norm1 (vit.cpp:808-812)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
             if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // qkv projection (vit.cpp:820-821)
-        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, w.qkv_w, w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV]))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
             if (!(c->skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873)
-        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, w.proj_w, w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, Wl[W_PROJ], w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4, Fl[W_PROJ]))) return rc;
         {   // norm2 (vit.cpp:881-885)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
             if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // MLP (vit.cpp:889-900)
-        if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, w.fc1_w, w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2))) return rc;
-        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, w.fc2_w, w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1]))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2]))) return rc;
         if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D
@@ -344,7 +442,12 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     // classifier (vit.cpp:927-928) and class softmax (vit.cpp:931-933)
     float *lg = d_logits ? (float *)d_logits : sl.logits;
     const int ldl = d_logits ? c->C : c->C_pad;
-    if ((rc = gemm(c, tn_, st, PC_GEMM_HEAD, EPI_BIAS_F32, sl.Z, c->head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4))) return rc;
+    const void *head_w = c->head_w; const QuantW *head_f = nullptr;
+    if (c->head_q.blocks) {
+        if (fused_ok(c->head_q, round_up(n, tm))) head_f = &c->head_q;
+        else { const QuantW *todo[1] = {&c->head_q}; void *dst[1] = {sl.Wq_head}; if ((rc = expand(todo, dst, 1))) return rc; head_w = sl.Wq_head; }
+    }
+    if ((rc = gemm(c, tn_, st, PC_GEMM_HEAD, EPI_BIAS_F32, sl.Z, head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4, head_f))) return rc;
     {
         ProfScope ps(c, st, PC_SOFTMAX, 0, (double)n * c->C * 8);
         HIP_TRY(launch_softmax(dt, lg, (float *)d_probs, n, c->C, ldl, st));
@@ -519,6 +622,28 @@ int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *b
     if (epi < 0 || epi > 3 || N % 64) { set_error("vitx_op_gemm: epi 0..3, N %% 64 == 0"); return VITX_ERR_ARG; }
     return op_gemm_impl(dtype, epi, 0, a, w, bias, out, nullptr, M, M, N, round_up(N, gemm_tile_n()), K, 0, stream);   // W and bias hold N rounded up to 128 rows
 }
+// quantised-weight kernels (quant.hip, gemm_nt_kernel<.., Q4>): blocks in the FILE's byte layout for every type except q4_0, whose
+// nibble plane / scale plane split is done here the way the context does it at upload
+int vitx_op_dequant(int dtype, int qtype, const void *blocks, const void *scales, void *out, int N, int n_pad, int K, void *stream) {
+    if (!blocks || !out || N <= 0 || n_pad < N || K <= 0 || K % 32 || (dtype != VITX_F16 && dtype != VITX_BF16)) { set_error("vitx_op_dequant: invalid argument"); return VITX_ERR_ARG; }
+    DequantJob j{blocks, scales, out, N, n_pad, K / 32};
+    hipError_t e = launch_dequant(dtype, qtype, &j, 1, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_op_dequant: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_ARG : VITX_ERR_HIP; }
+    return VITX_OK;
+}
+int vitx_op_gemm_q4(int dtype, int epi, const void *a, const void *qs, const void *scales, const void *bias, void *out, int M, int M_real, int N, int K, void *stream) {
+    if (!a || !qs || !scales || !bias || !out || epi < 0 || epi > EPI_BIAS_F32 || M_real <= 0 || M_real > M) { set_error("vitx_op_gemm_q4: invalid argument"); return VITX_ERR_ARG; }
+    if (!tuning_for_device(-1)) { set_error("vitx_op_gemm_q4: kernel bring-up failed"); return VITX_ERR_HIP; }
+    GemmArgs g{};
+    g.A = a; g.W = qs; g.Wscale = (const uint16_t *)scales; g.bias = (const float *)bias; g.out = out;
+    g.M = M; g.M_real = M_real; g.N = N; g.N_pad = round_up(N, 128); g.K = K; g.lda = K; g.ldw = K; g.ldo = N;
+    hipError_t e = launch_gemm_q4(dtype, epi, g, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) { set_error("vitx_op_gemm_q4: M %% 128, K %% 64 must be 0 (M %d N %d K %d)", M, N, K); return VITX_ERR_UNSUPPORTED; }
+    if (e != hipSuccess) { set_error("vitx_op_gemm_q4: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
+size_t vitx_ctx_weight_bytes(const vitx_ctx *c) { return c ? c->weight_bytes : 0; }
+
 int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
     if (!qkv || !out || n_img <= 0 || kernel < 0 || (kernel & 15) > 3) return VITX_ERR_ARG;
     const Tuning *t0 = tuning_for_device(-1);

@@ -54,6 +54,9 @@ constexpr int LEAD = 4;                 // stages allowed in flight past a phase
 }  // namespace pp
 
 template <int N> __device__ __forceinline__ void pp_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// counted vector-memory wait + every LDS read of this wave landed (the two-burst schedule re-stages a half-tile one burst after
+// its last read: the reads must be complete BEFORE the barrier that releases the other wave row's stage issue)
+template <int N> __device__ __forceinline__ void pp_wait_vm_lgkm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 // ---- epilogue of one wave's 128 x 64 block.  Swapped-product C layout: lane -> row l31 of each 32-row block,
@@ -404,11 +407,46 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         PP_PHASE((void)0, stage_w(0, off_b(B, 0)), W8, 1, 0, f, zero_quadrant(1, 0))                                          // C10 ; B0 two K-tiles ahead
         if (f) relaxed = false;
     };
+    // ---- two-burst schedule (FLAGS & 4096): the same operand stream, fragments and MFMA order with HALF the barriers.
+    // A K-tile is two bursts of 16 MFMAs: Q0 = C00 + C01 (reads A0, B0, B1), Q1 = C11 + C10 (reads A1; B0/B1 stay in registers).
+    // Stream order is unchanged (A0 B0 B1 A1 per K-tile): Q0 stages A1 of the next K-tile, Q1 stages A0 B0 B1 two K-tiles ahead
+    // (into the buffer whose A0/B0/B1 slots this K-tile's Q0 just read), so every stage has two bursts to land and
+    // s_waitcnt vmcnt(8) is uniform; the wait also drains this wave's LDS reads (see pp_wait_vm_lgkm).
+#define PP_BURST(READS, STAGE, FIRST, FIRST_STMT, MMA)                                                        \
+    {                                                                                      \
+        if (!(FLAGS & 8)) { READS; }                                                       \
+        if (FIRST) { FIRST_STMT; }                                                         \
+        if (!(FLAGS & 4)) { STAGE; }                                                       \
+        if (FIRST) { if (relaxed) pp_wait_vm_lgkm<W8B + 1 + pp_epi_stores<EPI>()>(); else pp_wait_vm_lgkm<W8B + 1>(); }   \
+        else pp_wait_vm_lgkm<W8B>();                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        pp_barrier();                                                                      \
+        stamp();                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(1);                                   \
+        if (!(FLAGS & 16)) { MMA; }                                                        \
+        if (!(FLAGS & 1)) __builtin_amdgcn_s_setprio(0);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        pp_barrier();                                                                      \
+        stamp();                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }
+    auto ktile2 = [&](auto bc, bool first) {
+        constexpr int B = decltype(bc)::value;
+        constexpr int W8B = 4 * STAGE_OPS;           // A1 of the next K-tile + A0 B0 B1 two K-tiles ahead may stay in flight
+        const bool f = B == 0 && first;
+        PP_BURST((read_a(B, 0), read_b(B, 0), read_b(B, 1)), (stage_a(1, off_a(B ^ 1, 1)), advance()), f,
+                 (zero_quadrant(0, 0), zero_quadrant(0, 1), stage_bias()), (mma(0, 0, 0, 8), mma(0, 1, 0, 8)))
+        PP_BURST(read_a(B, 1), (stage_a(0, off_a(B, 0)), stage_w(0, off_b(B, 0)), stage_w(1, off_b(B, 1))), f,
+                 (zero_quadrant(1, 1), zero_quadrant(1, 0)), (mma(1, 1, 0, 8), mma(1, 0, 0, 8)))
+        if (f) relaxed = false;
+    };
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
 
     // ---- prologue: A0 B0 B1 A1 of K-tile 0 and A0 B0 of K-tile 1 in flight, the first two landed
     stage_a(0, off_a(0, 0)); stage_w(0, off_b(0, 0)); stage_w(1, off_b(0, 1)); stage_a(1, off_a(0, 1)); advance();     // nkt >= 2: K-tile 1 exists
     stage_a(0, off_a(1, 0)); stage_w(0, off_b(1, 0));
+    if constexpr ((FLAGS & 4096) != 0) stage_w(1, off_b(1, 1));     // two-burst schedule: A0 B0 B1 of K-tile 1 precede its Q0; K-tile 0 complete but A1
     pp_wait_vmcnt<4 * STAGE_OPS>();
     pp_barrier();
     if (!(FLAGS & 2) && wr == 1) pp_barrier();      // the second wave row runs one barrier behind the first
@@ -418,7 +456,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         bias_so = __builtin_amdgcn_readfirstlane((n0 + wc * 64) * 4);
         for (int kt = 0; kt < nkt; kt += 2) {
             if constexpr ((FLAGS & (32 | 64 | 1024)) != 0) { if (round == 0 && kt == 4) n_stamp = 0; }
-            ktile(I0{}, kt == 0); ktile(I1{}, false);
+            if constexpr ((FLAGS & 4096) != 0) { ktile2(I0{}, kt == 0); ktile2(I1{}, false); }
+            else { ktile(I0{}, kt == 0); ktile(I1{}, false); }
         }
         if constexpr ((FLAGS & 8) != 0) {           // fragments never read: keep the MFMA operands "defined" for the compiler
             if (round == 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(fa[ii][ks])); asm volatile("" : "+v"(fb[ii][ks])); } }
@@ -445,6 +484,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     pp_wait_vmcnt<0>();                             // the trailing (unused) stages must land before the LDS allocation is released
     if constexpr ((FLAGS & (32 | 64 | 1024)) != 0) ((unsigned *)g.pos)[((size_t)bid * 8 + wave) * 64 + lane] = stamps;
 #undef PP_PHASE
+#undef PP_BURST
 }
 
 bool gemm_pp_supports(const GemmArgs &a) {
@@ -469,6 +509,16 @@ static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream
 }
 template <typename T>
 static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags, bool prepare) {
+    if (flags == 4096) {       // two-burst schedule: every epilogue
+        switch (epi) {
+        case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 4096>(a, n_cu, stream, prepare);
+        case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 4096>(a, n_cu, stream, prepare);
+        case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 4096>(a, n_cu, stream, prepare);
+        case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 4096>(a, n_cu, stream, prepare);
+        case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 4096>(a, n_cu, stream, prepare);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (flags) {       // experiment builds exist for the plain bias epilogue only
         if (epi != EPI_BIAS) return hipErrorInvalidValue;
         switch (flags) {
@@ -495,6 +545,13 @@ static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t 
         case 1028: return launch_pp_inst<T, EPI_BIAS, 1028>(a, n_cu, stream, prepare);
         case 1032: return launch_pp_inst<T, EPI_BIAS, 1032>(a, n_cu, stream, prepare);
         case 1036: return launch_pp_inst<T, EPI_BIAS, 1036>(a, n_cu, stream, prepare);
+        case 4097: return launch_pp_inst<T, EPI_BIAS, 4097>(a, n_cu, stream, prepare);
+        case 4100: return launch_pp_inst<T, EPI_BIAS, 4100>(a, n_cu, stream, prepare);
+        case 4104: return launch_pp_inst<T, EPI_BIAS, 4104>(a, n_cu, stream, prepare);
+        case 4108: return launch_pp_inst<T, EPI_BIAS, 4108>(a, n_cu, stream, prepare);
+        case 4128: return launch_pp_inst<T, EPI_BIAS, 4128>(a, n_cu, stream, prepare);
+        case 4140: return launch_pp_inst<T, EPI_BIAS, 4140>(a, n_cu, stream, prepare);
+        case 6144: return launch_pp_inst<T, EPI_BIAS, 6144>(a, n_cu, stream, prepare);
         default: return hipErrorInvalidValue;
         }
     }

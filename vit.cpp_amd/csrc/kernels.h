@@ -27,7 +27,23 @@ struct GemmArgs {
     int lda, ldw, ldo;
     int tpi;      // EPI_PATCH: patch tokens per image (g*g)
     int dbg;      // ablation bits for kernel experiments (VITX_GEMM_DBG): 1 no DMA in loop, 2 no ds_read in loop, 4 no MFMA, 8 no epilogue
+    // q4_0 weights kept in block form (launch_gemm_q4 only): W = nibble plane [N_pad][K/2] bytes (16 per block), Wscale = f16 block
+    // scales [N_pad][K/32]; both planes are the file's block_q4_0 fields re-laid out, 4.5 bits per weight
+    const uint16_t *Wscale;
 };
+
+// ---- block-quantised weights resident in HBM (quant.hip) -------------------------------------------
+// ggml block types of the reference's quantised files (vit.cpp:384-414 picks the type, quantize.cpp:271-303 writes it)
+enum { QT_Q4_0 = 2, QT_Q4_1 = 3, QT_Q5_0 = 6, QT_Q5_1 = 7, QT_Q8_0 = 8 };
+// One matrix to expand: `src` holds N rows of nbk blocks in the file's layout (q4_0: the two planes described at GemmArgs::Wscale,
+// scales at `scales`), dst is [n_pad][nbk * 32] in the operand type; rows N..n_pad are written as zeros.
+struct DequantJob { const void *src; const void *scales; void *dst; int N, n_pad, nbk; };
+// Expands up to 4 matrices of one block type in ONE launch: value = exactly what HostTensor::decode_f32 computes, rounded once (RNE) to
+// the operand type -- bit-identical to the host-side expansion at upload.
+hipError_t launch_dequant(int dtype, int qtype, const DequantJob *jobs, int njobs, hipStream_t stream);
+// C = A . dequant(W)^T with the q4_0 blocks expanded inside the GEMM's LDS-fill path (128x128x64 tiles; any epilogue)
+hipError_t launch_gemm_q4(int dtype, int epi, const GemmArgs &a, hipStream_t stream);
+bool gemm_q4_supports(const GemmArgs &a);
 
 // Per-device launch parameters.  Everything a launcher used to keep in function-local statics (CU count, "dynamic LDS
 // attribute already set", getenv results) lives here: one immutable copy per device, built by tuning_for_device() under a
@@ -40,6 +56,7 @@ struct Tuning {
     int gemm_stream = 1;     // VITX_GEMM_STREAM=0: one workgroup per tile (445) instead of the persistent 945 when the ring kernels run
     int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
     int gemm_split = 0;      // VITX_GEMM_SPLIT=1: tail rows of a partial round re-tiled 128x256 in a second launch (r01 default; off since the persistent kernel)
+    int pp_flags = 0;        // VITX_PP_SCHED=2: the two-burst schedule of the ping-pong kernel (gemm_pp.hip FLAGS 4096) instead of the four-phase one
     int gemm_balance = 1;    // VITX_GEMM_BALANCE=0: launch one workgroup per CU even when the last round of tiles is partial
     int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
     int attn_flags = 0;      // ablation build of the pipelined attention kernel (tools/attn_bench.py); 0 = product

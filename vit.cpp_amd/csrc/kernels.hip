@@ -28,7 +28,13 @@ constexpr int G_TILE_BYTES = GBM * GBK * 2;            // 16 KiB per operand til
 constexpr int G_STAGE_BYTES = 2 * G_TILE_BYTES;        // A + W
 constexpr int G_LDS_BYTES = 2 * G_STAGE_BYTES;         // double buffer: 64 KiB
 
-template <typename T, int EPI>
+// Q4 = true: W stays in ggml q4_0 block form in HBM (GemmArgs::W = nibble plane, ::Wscale = f16 block scales, 4.5 bits per weight) and
+// is expanded in the LDS-fill path: every thread loads ONE block (16 B of nibbles + its scale) of the next K-tile into registers
+// while the current K-tile is multiplied, then writes (q - 8) * d, rounded once to the operand type exactly as the host-side
+// expansion does (HostTensor::decode_f32 + RNE), into the same swizzled LDS image the LDS-DMA path produces.  The reference keeps
+// quantised weights through compute the same way (ggml_mul_mat on a q4_0 src0: /root/reference/vit.cpp:645-678, 820).
+typedef unsigned q4_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T, int EPI, bool Q4 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -57,7 +63,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_global_load_lds(GPTR(A + aoff[i] + k0), LPTR(base + i * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GPTR(W + woff[i] + k0), LPTR(base + G_TILE_BYTES + i * 4096), 16, 0, 0);
+            if constexpr (!Q4) __builtin_amdgcn_global_load_lds(GPTR(W + woff[i] + k0), LPTR(base + G_TILE_BYTES + i * 4096), 16, 0, 0);
+        }
+    };
+    // q4_0 path: thread -> (tile row tid / 2, block tid % 2 of the 64-deep K-tile)
+    const int q_row = tid >> 1, q_kb = tid & 1;
+    const int q_nbk = g.K >> 5;
+    const unsigned char *q_qs = (const unsigned char *)g.W + (size_t)(n0 + q_row) * q_nbk * 16;
+    const uint16_t *q_d = g.Wscale + (size_t)(n0 + q_row) * q_nbk;
+    q4_u32x4 q_regs = {0, 0, 0, 0}; uint16_t q_scale = 0;
+    auto load_q4 = [&](int kt) {
+        const int b = kt * 2 + q_kb;
+        q_regs = *(const q4_u32x4 *)(q_qs + (size_t)b * 16);
+        q_scale = q_d[b];
+    };
+    auto write_q4 = [&](int buf) {
+        const float d = (float)__builtin_bit_cast(_Float16, q_scale);
+        char *wt = smem + buf * G_STAGE_BYTES + G_TILE_BYTES;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {        // block elements 8 sl .. 8 sl + 7: low nibbles of bytes 0-15 first, then the high nibbles (block_q4_0)
+            typename Elem<T>::v8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int byte = (sl & 1) * 8 + e;
+                const unsigned w = q_regs[byte >> 2] >> ((byte & 3) * 8);
+                const int nib = (sl < 2) ? (int)(w & 15u) : (int)((w >> 4) & 15u);
+                v[e] = (T)((float)(nib - 8) * d);
+            }
+            *(typename Elem<T>::v8 *)(wt + swz_byte(q_row, q_kb * 4 + sl)) = v;
         }
     };
 
@@ -82,11 +115,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 
     const int nk = g.K / GBK;
     stage(0, 0);
+    if constexpr (Q4) { load_q4(0); write_q4(0); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * GBK);
+        if (kt + 1 < nk) { stage(cur ^ 1, (kt + 1) * GBK); if constexpr (Q4) load_q4(kt + 1); }
         const char *sb = smem + cur * G_STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -101,6 +135,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mfma(af[i], wf[j], acc[i][j]);
         }
+        if constexpr (Q4) { if (kt + 1 < nk) write_q4(cur ^ 1); }     // the other buffer: every wave finished reading it before the previous barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -140,14 +175,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 int gemm_tile_m() { return 256; }   // row padding of every activation buffer (ring kernel tile height)
 int gemm_tile_n() { return GBN; }
 
-template <typename T>
+template <typename T, bool Q4 = false>
 static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream, bool prepare) {
     const int grid = prepare ? 1 : (a.M / GBM) * (a.N_pad / GBN);
     const dim3 blk(256);
 #define VITX_GEMM_CASE(E)                                                                                   \
     case E: {                                                                                               \
-        if (prepare) return hipFuncSetAttribute((const void *)gemm_nt_kernel<T, E>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES); \
-        hipLaunchKernelGGL((gemm_nt_kernel<T, E>), dim3(grid), blk, G_LDS_BYTES, stream, a);                \
+        if (prepare) return hipFuncSetAttribute((const void *)gemm_nt_kernel<T, E, Q4>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES); \
+        hipLaunchKernelGGL((gemm_nt_kernel<T, E, Q4>), dim3(grid), blk, G_LDS_BYTES, stream, a);            \
     } break;
     switch (epi) {
         VITX_GEMM_CASE(EPI_BIAS)
@@ -184,14 +219,14 @@ static int pp_grid(const Tuning &t, const GemmArgs &a) {
 }
 
 static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
-    if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream);
+    if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(t, a), stream);
 }
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
     int cfg = t.gemm_cfg;
-    if (cfg == 1) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream);
+    if (cfg == 1) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     if (cfg > 1) return gemm_ring_supports(a, cfg) ? launch_gemm_ring(t, dtype, epi, a, cfg, stream) : hipErrorInvalidValue;
     if (cfg < 0) {
         const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
@@ -226,6 +261,12 @@ hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, h
     }
     if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
     return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream, false) : launch_gemm_t<__bf16>(epi, a, stream, false);
+}
+
+bool gemm_q4_supports(const GemmArgs &a) { return a.Wscale && a.M > 0 && a.M % GBM == 0 && a.N_pad % GBN == 0 && a.K % GBK == 0; }
+hipError_t launch_gemm_q4(int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
+    if (!gemm_q4_supports(a)) return hipErrorInvalidValue;
+    return dtype == DT_F16 ? launch_gemm_t<_Float16, true>(epi, a, stream, false) : launch_gemm_t<__bf16, true>(epi, a, stream, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -958,8 +999,9 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
     for (int dt = 0; dt < 2; ++dt) {
         for (int epi = 0; epi <= EPI_PATCH; ++epi) {
             for (int cfg : {945, 445, 245, 122}) if ((e = launch_gemm_ring(t, dt, epi, none, cfg, nullptr, true)) != hipSuccess) return e;
-            if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
+            for (int fl : {0, 4096}) if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, fl, true)) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
+            if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16, true>(epi, none, nullptr, true) : launch_gemm_t<__bf16, true>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
         if ((e = (dt == DT_F16 ? launch_attention_stream<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_stream<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_flow<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_flow<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
@@ -993,6 +1035,7 @@ const Tuning *tuning_for_device(int device) {
     t->gemm_skinny = getenv("VITX_GEMM_NOSKINNY") == nullptr;
     t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);      // r02: with the persistent ping-pong kernel the two-launch tail split costs 5 % of the step (profiles/r02_forward_sweeps.txt)
     t->gemm_balance = env_int("VITX_GEMM_BALANCE", 1);
+    t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : 0;
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
     const hipError_t e = prepare_device_kernels(*t);
