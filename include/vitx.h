@@ -167,7 +167,8 @@ int vitx_op_layernorm(int dtype, const void *d_x, const void *d_w, const void *d
  * M must be a multiple of 128 rows allocated; N, K multiples of 64. */
 int vitx_op_gemm(int dtype, int epi, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int M, int N, int K, void *stream);
 /* The same with an explicit kernel family, so every production GEMM variant can be checked against a numeric reference:
- *   kernel 0 = automatic (what the forward would pick for this shape), 1 = ping-pong persistent 256x256 kernel (gemm_pp.hip),
+ *   kernel 0 = automatic (what the forward would pick for this shape), 1 = ping-pong persistent 256x256 kernel (gemm_pp.hip) with
+ *   its four-phase K-tile schedule, 3 = the same kernel with the two-burst schedule (16-MFMA bursts, half the barriers),
  *   945 / 445 = ring kernels with 256x256 tiles (persistent / one workgroup per tile), 245 = 128x256, 122 = skinny 64x128,
  *   2 = the automatic choice with the tail split forced on (rows of a partial round re-tiled 128x256 in a second launch).
  * Adds epi 4 (patch embedding, vit.cpp:772-797): out f32 [M + M/tpi + 1 rows] : row m -> row m + m/tpi + 1, + d_pos[(m % tpi) + 1][n];

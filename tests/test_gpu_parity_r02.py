@@ -32,7 +32,7 @@ def _gelu_ref(x):
 # GEMM: all kernel families
 # ------------------------------------------------------------------------------------------------------------------
 M_BIG, TPI = 33280, 196            # 130 row tiles of 256; 169 whole "images" of 196 patch rows + a ragged rest
-KERNELS = [1, 945, 445, 245, 122, 0, 2]
+KERNELS = [1, 3, 945, 445, 245, 122, 0, 2]          # vitx_op_gemm_ex kernel ids (1 / 3 = ping-pong kernel, four-phase / two-burst schedule)
 
 
 @pytest.mark.parametrize("dtype_name", ["f16", "bf16"])
@@ -104,7 +104,7 @@ def test_gemm_every_kernel_family_and_epilogue(binding, torch_gpu, kernel, dtype
 @pytest.mark.parametrize("dtype_name", ["f16", "bf16"])
 def test_gemm_kernel_families_are_bit_identical(binding, torch_gpu, dtype_name):
     """Every family consumes K in the same order with the same MFMA, so they agree BIT FOR BIT (this is what makes results
-    independent of the batch size, which decides the family): ping-pong vs ring 945 / 245 / 122 on all epilogues."""
+    independent of the batch size, which decides the family): ping-pong (both K-tile schedules) vs ring 945 / 245 / 122 on all epilogues."""
     torch = torch_gpu
     dt = binding.F16 if dtype_name == "f16" else binding.BF16
     tdt = torch.float16 if dtype_name == "f16" else torch.bfloat16
@@ -117,7 +117,7 @@ def test_gemm_kernel_families_are_bit_identical(binding, torch_gpu, dtype_name):
     L = binding.lib()
     for epi in (0, 1, 2, 3):
         outs = []
-        for kernel in (1, 945, 245, 122):
+        for kernel in (1, 3, 945, 245, 122):
             out = resid.clone() if epi >= 2 else torch.zeros((M, N), dtype=tdt, device="cuda")
             binding.check(L.vitx_op_gemm_ex(dt, epi, kernel, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), None, M, M, N, K, 0, None))
             torch.cuda.synchronize()

@@ -136,7 +136,7 @@ def test_quantised_context_keeps_blocks_in_hbm(pkg, binding, oracle, torch_gpu, 
     # the patch-embedding kernel stays f16 in a quantised file (4-D tensor, quantize.cpp:207-223), so the ratio is a little above bits/16
     assert jit_b <= ratio * host_b, (jit_b, host_b)
     if ftype == 2:
-        fus_p, fus_l, fus_b = _ctx_forward(binding, p, imgs[:3], binding.F16, 3, {})                            # 3 images: 768 rows -> fused kernel
+        fus_p, fus_l, fus_b = _ctx_forward(binding, p, imgs[:3], binding.F16, 3, {"VITX_Q4_FUSED_ROWS": "4096"})  # 3 images: 768 rows -> fused kernel
         assert fus_b == jit_b
         assert np.abs(fus_p - host_p[:3]).max() <= 2e-4
         _, want = oracle.OracleModel(p).forward(imgs[:3], dataclasses.replace(oracle.REF, quant_act=0))

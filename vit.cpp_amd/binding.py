@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("VITX_LIB") or os.path.join(_HERE, "libvitx.so")   # V
 F16, BF16 = 0, 1
 BICUBIC, BILINEAR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH = 0, 1, 2, 3, 4
-GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT = 0, 1, 2          # vitx_op_gemm_ex `kernel` (or a ring configuration: 945, 445, 245, 122)
+GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT, GEMM_PP_TWO_BURST = 0, 1, 2, 3          # vitx_op_gemm_ex `kernel` (or a ring configuration: 945, 445, 245, 122)
 
 EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",

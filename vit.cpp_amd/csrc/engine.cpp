@@ -74,7 +74,10 @@ struct vitx_ctx {
     std::vector<LayerW> layers;
     // quantised files: VITX_QUANT_HOST=1 restores the r01 behaviour (expand once on the host at upload, 16 bits per weight in HBM)
     bool quant_on_device = true;
-    int q4_fused_rows = 4096;            // q4_0 GEMMs with at most this many rows expand the blocks inside the GEMM (VITX_Q4_FUSED_ROWS)
+    // q4_0 GEMMs with at most this many rows expand the blocks inside the GEMM's LDS-fill path (VITX_Q4_FUSED_ROWS).  0 = never: measured
+    // on ViT-B (profiles/r02c_quant.txt) the 128x128-tile fused kernel loses to "expand the layer just in time, then the skinny ring
+    // kernels" at every batch size (batch 1: 1.75 vs 1.06 ms, batch 8: 2.15 vs 1.33 ms), so it is an option, not the default.
+    int q4_fused_rows = 0;
     size_t weight_bytes = 0;             // device bytes held by weight matrices (vitx_ctx_weight_bytes)
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
@@ -605,7 +608,9 @@ static int op_gemm_impl(int dtype, int epi, int kernel, const void *a, const voi
     const Tuning *t0 = tuning_for_device(-1);
     if (!t0) { set_error("vitx_op_gemm: kernel bring-up failed"); return VITX_ERR_HIP; }
     Tuning t = *t0;
-    if (kernel == 2) t.gemm_split = 1; else if (kernel != 0) t.gemm_cfg = kernel;
+    if (kernel == 2) t.gemm_split = 1;
+    else if (kernel == 1 || kernel == 3) { t.gemm_cfg = 1; t.pp_flags = kernel == 3 ? 4096 : 0; }      // ping-pong kernel: four-phase / two-burst schedule
+    else if (kernel != 0) t.gemm_cfg = kernel;
     // W (and bias) must hold n_pad rows; rows beyond N are never stored
     GemmArgs g{};
     g.A = a; g.W = w; g.bias = (const float *)bias; g.out = out; g.pos = (const float *)pos;
