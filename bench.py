@@ -198,6 +198,19 @@ def main():
                                "frac": round(tf / PEAK_TFLOPS, 4), "traffic": traffic.get(dom["name"]), "traffic_unit": "GB per launch",
                                "traffic_source": traffic_src,
                                "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "flops_per_launch": dom["flops"] / dom["launches"]}
+            # what the matrix pipe of THIS device sustains on non-trivial operand values under its power cap (vitx_probe_mfma:
+            # back-to-back MFMAs on register operands, uniform random fill, no memory traffic): `peak` above stays the nominal
+            # 2516.6 TFLOP/s the contract asks for; this is the measured ceiling the same silicon reaches in the best case
+            if world == 1 and not os.environ.get("VITX_NO_MFMA_PROBE"):
+                try:
+                    ptf, pmhz = binding.probe_mfma(local_rank, dt, 2, 150.0)
+                    out["roofline"]["mfma_sustained_random_operands"] = {
+                        "TFLOPs": round(ptf, 1), "shader_clock_MHz": round(pmhz), "frac_of_it": round(tf / ptf, 4),
+                        "what": "vitx_probe_mfma: 8 waves/CU of back-to-back v_mfma_f32_32x32x16 on register operands (uniform random values), ~150 ms; "
+                                "the package sits at its 1400 W cap and the clock drops below the nominal 2400 MHz (zero-filled operands: ~2480 TFLOP/s)"}
+                    out["mfma_sustained_frac_whole_forward"] = round(value / world * gflop / 1e3 / ptf, 4)
+                except Exception as e:      # the probe is informative only
+                    out["roofline"]["mfma_sustained_random_operands"] = {"error": str(e)}
             out["roofline"]["launches_per_step"] = dom["launches"] / prof_steps
             out["roofline"]["measured_over"] = f"last {prof_steps} of the {args.steps} timed steps"
             out["roofline"]["schedule"] = "profiled steps: sub-batches serialised on one stream; other steps: 2 sub-batches on 2 HIP streams"

@@ -64,6 +64,7 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
     fill_f32<<<2048, 256>>>((float *)out, (size_t)M * N * out_elem / 4, 4u, epi == EPI_BIAS_RESID ? 1.0f : 0.0f);
     CK(hipDeviceSynchronize());
     g.A = A; g.W = W; g.bias = bias; g.out = out; g.pos = nullptr; g.M = M; g.M_real = M; g.N = N; g.N_pad = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = 0;
+    if (const char *e = getenv("LAB_GROUP_M")) g.group_m = atoi(e);
     unsigned *tl = nullptr;
     if (v.kind == 1 && (v.cfg & (96 | 1024))) { CK(hipMalloc(&tl, 256 * 8 * 64 * 4)); CK(hipMemset(tl, 0, 256 * 8 * 64 * 4)); g.pos = (const float *)tl; }
     if (v.kind == 1 && (v.cfg & (28 | 2048 | 16384))) check = false;      // ablation builds compute garbage on purpose

@@ -26,7 +26,7 @@ EXPORTS = [
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_image_load", "vitx_image_decode", "vitx_image_free", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
-    "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes",
+    "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_probe_mfma",
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
         L.vitx_op_dequant.argtypes = [ip, ip, vp, vp, vp, ip, ip, ip, vp]
         L.vitx_op_gemm_q4.argtypes = [ip, ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, vp]
         L.vitx_ctx_weight_bytes.restype = C.c_size_t; L.vitx_ctx_weight_bytes.argtypes = [vp]
+        L.vitx_probe_mfma.argtypes = [ip, ip, ip, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -278,6 +279,13 @@ class Group:
             self.close()
         except Exception:
             pass
+
+
+def probe_mfma(device: int = 0, dtype: int = BF16, fill: int = 2, target_ms: float = 150.0) -> Tuple[float, float]:
+    """(TFLOP/s, shader MHz) of back-to-back MFMAs on register operands: the power-managed ceiling of the matrix pipe (vitx_probe_mfma)."""
+    tf = C.c_double(); mhz = C.c_double()
+    check(lib().vitx_probe_mfma(device, dtype, fill, target_ms, C.byref(tf), C.byref(mhz)), "vitx_probe_mfma")
+    return tf.value, mhz.value
 
 
 def topk(probs_row: np.ndarray, k: int = 5):

@@ -231,14 +231,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     const int my_tiles = (ntiles - bid + nblk - 1) / nblk;
     const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7;
     const int lid_base = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8);
+    const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;
     auto tile_origin = [&](int round, int &m0, int &n0) {
         const int v = bid + round * nblk;
         const int lid = lid_base + (v >> 3);
-        const int per_group = GROUP_M * ntn;
+        const int per_group = group_m * ntn;
         const int grp = lid / per_group, within = lid - grp * per_group;
-        const int gm = min(GROUP_M, ntm - grp * GROUP_M);
+        const int gm = min(group_m, ntm - grp * group_m);
         const int tn = within / gm;
-        m0 = (grp * GROUP_M + (within - tn * gm)) * BM; n0 = tn * BN;
+        m0 = (grp * group_m + (within - tn * gm)) * BM; n0 = tn * BN;
     };
     if (my_tiles <= 0) return;
 

@@ -30,6 +30,7 @@ struct GemmArgs {
     // q4_0 weights kept in block form (launch_gemm_q4 only): W = nibble plane [N_pad][K/2] bytes (16 per block), Wscale = f16 block
     // scales [N_pad][K/32]; both planes are the file's block_q4_0 fields re-laid out, 4.5 bits per weight
     const uint16_t *Wscale;
+    int group_m;  // ping-pong kernel: m-tiles per raster group (0 = the default, 8); VITX_GROUP_M / LAB_GROUP_M experiments
 };
 
 // ---- block-quantised weights resident in HBM (quant.hip) -------------------------------------------
@@ -57,6 +58,7 @@ struct Tuning {
     int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
     int gemm_split = 0;      // VITX_GEMM_SPLIT=1: tail rows of a partial round re-tiled 128x256 in a second launch (r01 default; off since the persistent kernel)
     int pp_flags = 0;        // VITX_PP_SCHED=2: the two-burst schedule of the ping-pong kernel (gemm_pp.hip FLAGS 4096) instead of the four-phase one
+    int group_m = 0;         // VITX_GROUP_M: raster group height of the ping-pong kernel (0 = its default)
     int gemm_balance = 1;    // VITX_GEMM_BALANCE=0: launch one workgroup per CU even when the last round of tiles is partial
     int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
     int attn_flags = 0;      // ablation build of the pipelined attention kernel (tools/attn_bench.py); 0 = product

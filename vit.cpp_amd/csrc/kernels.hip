@@ -218,7 +218,8 @@ static int pp_grid(const Tuning &t, const GemmArgs &a) {
     return (int)(g < cap ? g : cap);
 }
 
-static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
+static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a0, hipStream_t stream) {
+    GemmArgs a = a0; a.group_m = t.group_m;
     if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(t, a), stream);
 }
@@ -1036,6 +1037,7 @@ const Tuning *tuning_for_device(int device) {
     t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);      // r02: with the persistent ping-pong kernel the two-launch tail split costs 5 % of the step (profiles/r02_forward_sweeps.txt)
     t->gemm_balance = env_int("VITX_GEMM_BALANCE", 1);
     t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : 0;
+    t->group_m = env_int("VITX_GROUP_M", 0);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
     const hipError_t e = prepare_device_kernels(*t);
