@@ -71,6 +71,12 @@ int vitx_model_hparams(const vitx_model *m, vitx_hparams *out);
 int vitx_model_num_labels(const vitx_model *m);
 /* id2label lookup (vit.cpp:1065 uses .at(idx)); NULL when the id has no label. */
 const char *vitx_model_label(const vitx_model *m, int class_id);
+/* 3 for a ViT classifier file; 1 for a ViTSTR scene-text file (extensions/vitstr.cpp: the patch kernel is [P, P, 1, D],
+ * vitstr.cpp:482).  vitx_model_seq_len: 0 for a classifier (one probability row per image: the cls token), 25 for ViTSTR
+ * (the head reads tokens 0..24 of every image, vitstr.cpp:864-904: 25 probability rows per image). */
+#define VITX_VITSTR_SEQ_LEN 25
+int vitx_model_in_channels(const vitx_model *m);
+int vitx_model_seq_len(const vitx_model *m);
 int vitx_model_num_tensors(const vitx_model *m);
 /* Name, file type code (0 f32,1 f16,2 q4_0,3 q4_1,6 q5_0,7 q5_1,8 q8_0), ggml-order dims. */
 int vitx_model_tensor_info(const vitx_model *m, int index, const char **name, int32_t *type, int64_t ne[4], size_t *nbytes);
@@ -101,6 +107,14 @@ int vitx_preprocess_u8(const uint8_t *hwc, int nx, int ny, int img_size, int int
  * to vitx_preprocess_u8 (same operations in the same order, IEEE division, no FMA contraction). */
 int vitx_preprocess_u8_device(const void *d_hwc, int n, int nx, int ny, int img_size, int interp, void *d_out_hwc, void *stream);
 
+/* ViTSTR (extensions/vitstr.cpp) front and back end.  vitx_preprocess_vitstr_u8 replaces that extension's vit_image_preprocess
+ * (vitstr.cpp:135-201): RGB u8 HWC -> grey (PIL weights, truncated to u8) -> direct linear resize to img_size^2 -> [-1, 1]; out is
+ * ONE channel [img_size][img_size] f32 (nx, ny >= 2).  vitx_vitstr_decode replaces the greedy decode of its vit_predict
+ * (vitstr.cpp:1025-1051) on one image's [seq_len][num_classes] probabilities: ids gets the classes of the characters (at most
+ * seq_len - 1), *score the product of their probabilities; position 0 is skipped, class 1 ("[s]") ends the text. */
+int vitx_preprocess_vitstr_u8(const uint8_t *hwc, int nx, int ny, int img_size, float *out_hw);
+int vitx_vitstr_decode(const float *probs, int seq_len, int num_classes, int32_t *ids, int *n_ids, double *score);
+
 /* ---- execution context (replaces vit_state + the per-call graph build) ------ */
 /* Uploads the weights to `device` in `dtype` and allocates all activation scratch
  * for up to max_batch images once (the reference reallocates per call, vit.cpp:1009-1035).
@@ -111,6 +125,10 @@ int vitx_preprocess_u8_device(const void *d_hwc, int n, int nx, int ny, int img_
 int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out);
 void vitx_ctx_free(vitx_ctx *c);
 int vitx_ctx_max_batch(const vitx_ctx *c);
+/* Probability rows per image that vitx_forward / vitx_forward_device write: 1 for a classifier ([n][num_classes]), 25 for a ViTSTR
+ * file ([n][25][num_classes], row t = token t of the image; decode with vitx_vitstr_decode).  Images are then ONE grey channel:
+ * [img_size][img_size] f32, as vitx_preprocess_vitstr_u8 emits. */
+int vitx_ctx_out_rows(const vitx_ctx *c);
 
 /* Forward pass (replaces vit_encode_image + the compute half of vit_predict,
  * vit.cpp:718-941, 1028-1040) on n <= max_batch images.

@@ -75,6 +75,8 @@ def lib():
         L.oracle_tensor_f32.restype = fp; L.oracle_tensor_f32.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
         L.oracle_preprocess_bicubic.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, fp]
         L.oracle_preprocess_bilinear.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, fp]
+        L.oracle_preprocess_vitstr.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, fp]
+        L.oracle_model_in_chans.argtypes = [C.c_void_p]; L.oracle_model_out_rows.argtypes = [C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -93,6 +95,8 @@ class OracleModel:
         hp = (C.c_int * 7)(); lib().oracle_model_hparams(self._h, hp)
         self.D, self.L, self.H, self.C, self.P, self.S, self.ftype = list(hp)
         self.g = self.S // self.P; self.N = self.g * self.g + 1
+        self.in_chans = lib().oracle_model_in_chans(self._h)       # 3, or 1 for a ViTSTR file (extensions/vitstr.cpp)
+        self.out_rows = lib().oracle_model_out_rows(self._h)       # head rows per image: 1 (cls token) or 25 (ViTSTR)
 
     def close(self):
         if self._h:
@@ -103,10 +107,12 @@ class OracleModel:
         except Exception: pass
 
     def forward(self, img_hwc: np.ndarray, mode: Mode = REF, dump: bool = False):
-        """img_hwc: [n,S,S,3] f32 normalised.  Returns (logits [n,C], probs [n,C][, x_dump [L+1,n*N,D]])."""
+        """img_hwc: [n,S,S,3] f32 normalised ([n,S,S] grey for a ViTSTR file).  Returns (logits [n,C], probs [n,C][, x_dump
+        [L+1,n*N,D]]); a ViTSTR file gives [n,25,C]."""
         img = np.ascontiguousarray(img_hwc, np.float32)
-        n = img.shape[0]; assert img.shape[1:] == (self.S, self.S, 3)
-        logits = np.empty((n, self.C), np.float32); probs = np.empty((n, self.C), np.float32)
+        n = img.shape[0]; assert img.shape[1:] == ((self.S, self.S, 3) if self.in_chans == 3 else (self.S, self.S))
+        shape = (n, self.C) if self.out_rows == 1 else (n, self.out_rows, self.C)
+        logits = np.empty(shape, np.float32); probs = np.empty(shape, np.float32)
         xd = np.empty((self.L + 1, n * self.N, self.D), np.float32) if dump else None
         md = mode.c()
         rc = lib().oracle_forward(self._h, _fp(img), n, C.byref(md), _fp(logits), _fp(probs), _fp(xd) if dump else None)
@@ -140,7 +146,8 @@ class OracleModel:
 
     def head(self, X: np.ndarray, n_img: int, mode: Mode = REF):
         X = np.ascontiguousarray(X, np.float32); md = mode.c()
-        logits = np.empty((n_img, self.C), np.float32); probs = np.empty((n_img, self.C), np.float32)
+        shape = (n_img, self.C) if self.out_rows == 1 else (n_img, self.out_rows, self.C)
+        logits = np.empty(shape, np.float32); probs = np.empty(shape, np.float32)
         lib().oracle_head(self._h, _fp(X), _fp(logits), _fp(probs), n_img, C.byref(md))
         return logits, probs
 
@@ -170,6 +177,14 @@ def preprocess(img_u8: np.ndarray, S: int, mode: str = "bicubic") -> np.ndarray:
     out = np.empty((S, S, 3), np.float32)
     fn = lib().oracle_preprocess_bicubic if mode == "bicubic" else lib().oracle_preprocess_bilinear
     fn(img.ctypes.data_as(C.POINTER(C.c_uint8)), nx, ny, S, _fp(out))
+    return out
+
+
+def preprocess_vitstr(img_u8: np.ndarray, S: int) -> np.ndarray:
+    """vit_image_preprocess of extensions/vitstr.cpp: HWC u8 RGB -> [S,S] f32 grey in [-1, 1]."""
+    img = np.ascontiguousarray(img_u8, np.uint8); ny, nx = img.shape[:2]
+    out = np.empty((S, S), np.float32)
+    lib().oracle_preprocess_vitstr(img.ctypes.data_as(C.POINTER(C.c_uint8)), nx, ny, S, _fp(out))
     return out
 
 

@@ -190,6 +190,7 @@ typedef struct {
 
 typedef struct {
     int D, L, H, C, P, S, ftype;
+    int Cin, R;              /* input channels (3; 1 = ViTSTR file, extensions/vitstr.cpp/vitstr.cpp:482) and head rows per image (1; 25 = ViTSTR, :864-883) */
     int g, N;            /* patches per side, tokens */
     float eps;
     int n_labels; int *label_keys; char **labels;
@@ -288,6 +289,8 @@ omodel *oracle_model_load(const char *path) {
         m->n_tensors_loaded++;
     }
     fclose(f);
+    m->Cin = (m->pe_w.n_dims == 4 && m->pe_w.ne[2] == 1) ? 1 : 3;
+    m->R = m->Cin == 1 ? 25 : 1;
     if (m->n_tensors_loaded != 8 + 12 * L) { fprintf(stderr, "oracle: %d tensors, expected %d\n", m->n_tensors_loaded, 8 + 12 * L); oracle_model_free(m); return NULL; }
     init_tables();
     return m;
@@ -303,6 +306,8 @@ void oracle_model_free(omodel *m) {
     free(m->labels); free(m->label_keys); free(m);
 }
 
+int oracle_model_in_chans(const omodel *m) { return m->Cin; }
+int oracle_model_out_rows(const omodel *m) { return m->R; }
 void oracle_model_hparams(const omodel *m, int *out7) {
     out7[0] = m->D; out7[1] = m->L; out7[2] = m->H; out7[3] = m->C; out7[4] = m->P; out7[5] = m->S; out7[6] = m->ftype;
 }
@@ -455,7 +460,7 @@ void oracle_attention(const float *qkv, float *out, int n_img, int N, int D, int
  * = im2col to fp16 with k = c*P*P + ky*P + kx, dot with the fp16 kernel in f32, + bias
  * (773-775), token t = px + g*py (778-791), cls row prepended (794), + pos_embed (797). */
 void oracle_patch_embed(const omodel *m, const float *img_hwc, float *X, int n_img, const omode *md) {
-    const int D = m->D, P = m->P, S = m->S, g = m->g, N = m->N, K = 3 * P * P;
+    const int D = m->D, P = m->P, S = m->S, g = m->g, N = m->N, Cin = m->Cin, K = Cin * P * P;   /* ViTSTR: one grey plane (vitstr.cpp:713-731) */
     /* ggml's im2col always emits fp16 (kernel must be f16, vit.cpp:515) -> act rounding is at least fp16 unless 'ideal' */
     const int ar = md->act_round;
     float *wbuf = NULL;
@@ -468,9 +473,9 @@ void oracle_patch_embed(const omodel *m, const float *img_hwc, float *X, int n_i
 #pragma omp for schedule(static) collapse(2)
         for (int b = 0; b < n_img; ++b) for (int t = 0; t < g * g; ++t) {
             const int py = t / g, px = t % g;
-            const float *img = img_hwc + (size_t)b * S * S * 3;
-            for (int c = 0; c < 3; ++c) for (int ky = 0; ky < P; ++ky) for (int kx = 0; kx < P; ++kx)
-                col[c * P * P + ky * P + kx] = round_sel(img[((size_t)(py * P + ky) * S + (px * P + kx)) * 3 + c], ar);
+            const float *img = img_hwc + (size_t)b * S * S * Cin;
+            for (int c = 0; c < Cin; ++c) for (int ky = 0; ky < P; ++ky) for (int kx = 0; kx < P; ++kx)
+                col[c * P * P + ky * P + kx] = round_sel(img[((size_t)(py * P + ky) * S + (px * P + kx)) * Cin + c], ar);
             float *xr = X + ((size_t)b * N + 1 + t) * D;
             for (int n = 0; n < D; ++n) { float v = dot_f32(W + (size_t)n * K, col, K); v = v + m->pe_b.f32[n]; xr[n] = v + m->pos.f32[(size_t)(1 + t) * D + n]; }
         }
@@ -502,14 +507,15 @@ void oracle_layer(const omodel *m, int il, float *X, int n_img, const omode *md)
     free(U); free(QKV); free(O); free(Hh);
 }
 
-/* cls pooling + final LN + head + softmax (vit.cpp:910-933). */
+/* cls pooling + final LN + head + softmax (vit.cpp:910-933).  A ViTSTR file keeps the first R = 25 tokens of every image instead of
+ * the cls token alone (extensions/vitstr.cpp/vitstr.cpp:864-904): logits / probs are [n_img * R][C], row = image * R + token. */
 void oracle_head(const omodel *m, const float *X, float *logits, float *probs, int n_img, const omode *md) {
-    const int D = m->D, N = m->N, C = m->C;
-    float *cls = (float *)malloc((size_t)n_img * D * 4), *z = (float *)malloc((size_t)n_img * D * 4);
-    for (int b = 0; b < n_img; ++b) memcpy(cls + (size_t)b * D, X + (size_t)b * N * D, (size_t)D * 4);
-    oracle_layernorm(cls, m->norm_w.f32, m->norm_b.f32, z, n_img, D, m->eps);
-    oracle_linear(&m->head_w, m->head_b.f32, z, logits, n_img, md);
-    if (probs) { memcpy(probs, logits, (size_t)n_img * C * 4); oracle_softmax_rows(probs, n_img, C, md->lut); }
+    const int D = m->D, N = m->N, C = m->C, R = m->R, rows = n_img * R;
+    float *cls = (float *)malloc((size_t)rows * D * 4), *z = (float *)malloc((size_t)rows * D * 4);
+    for (int b = 0; b < n_img; ++b) memcpy(cls + (size_t)b * R * D, X + (size_t)b * N * D, (size_t)R * D * 4);
+    oracle_layernorm(cls, m->norm_w.f32, m->norm_b.f32, z, rows, D, m->eps);
+    oracle_linear(&m->head_w, m->head_b.f32, z, logits, rows, md);
+    if (probs) { memcpy(probs, logits, (size_t)rows * C * 4); oracle_softmax_rows(probs, rows, C, md->lut); }
     free(cls); free(z);
 }
 
@@ -589,6 +595,26 @@ void oracle_preprocess_bilinear(const uint8_t *src, int nx, int ny, int S, float
         const uint8_t v2 = (uint8_t)fminf(fmaxf(roundf(v), 0.0f), 255.0f);
         dst[3 * ((size_t)y * nx3 + x) + c] = ((float)v2 - m3[c]) / s3[c];
     }
+}
+
+/* vit_image_preprocess of the ViTSTR extension (extensions/vitstr.cpp/vitstr.cpp:128-201): grey = (uint8)(0.299 r + 0.587 g + 0.114 b)
+ * in double, direct resize with scale n / S, 2x2 linear blend anchored at the truncated source coordinate (clamped to n - 2),
+ * (v / 255 - 0.5) * 2; the padding loops start at res.nx == S and do nothing.  dst: [S][S] f32, one channel. */
+void oracle_preprocess_vitstr(const uint8_t *src, int nx, int ny, int S, float *dst) {
+    uint8_t *grey = (uint8_t *)malloc((size_t)nx * ny);
+    for (size_t i = 0; i < (size_t)nx * ny; ++i) grey[i] = (uint8_t)(0.299 * src[3 * i] + 0.587 * src[3 * i + 1] + 0.114 * src[3 * i + 2]);
+    const float x_scale = (float)nx / S, y_scale = (float)ny / S;
+    for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x) {
+        const float gx = x * x_scale, gy = y * y_scale;
+        const int gxi = (int)gx, gyi = (int)gy;
+        const float u = gx - gxi, v = gy - gyi;
+        int px0 = gxi < nx - 2 ? gxi : nx - 2; if (px0 < 0) px0 = 0;
+        int py0 = gyi < ny - 2 ? gyi : ny - 2; if (py0 < 0) py0 = 0;
+        float val = (1 - u) * (1 - v) * grey[(size_t)py0 * nx + px0] + u * (1 - v) * grey[(size_t)py0 * nx + px0 + 1] +
+                    (1 - u) * v * grey[(size_t)(py0 + 1) * nx + px0] + u * v * grey[(size_t)(py0 + 1) * nx + px0 + 1];
+        dst[(size_t)y * S + x] = (val / 255.0f - 0.5f) * 2.0f;
+    }
+    free(grey);
 }
 
 /* ------------------------------------------------------------- small utilities */

@@ -27,6 +27,7 @@ EXPORTS = [
     "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_probe_mfma",
+    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
 
 
@@ -102,6 +103,9 @@ def lib():
         L.vitx_op_gemm_q4.argtypes = [ip, ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, vp]
         L.vitx_ctx_weight_bytes.restype = C.c_size_t; L.vitx_ctx_weight_bytes.argtypes = [vp]
         L.vitx_probe_mfma.argtypes = [ip, ip, ip, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.vitx_model_in_channels.argtypes = [vp]; L.vitx_model_seq_len.argtypes = [vp]; L.vitx_ctx_out_rows.argtypes = [vp]
+        L.vitx_preprocess_vitstr_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, C.POINTER(C.c_float)]
+        L.vitx_vitstr_decode.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(ip), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -132,6 +136,10 @@ class Model:
         except Exception:       # interpreter shutdown: module globals may already be gone
             pass
 
+    @property
+    def in_channels(self) -> int: return lib().vitx_model_in_channels(self._h)      # 3, or 1 for a ViTSTR file
+    @property
+    def seq_len(self) -> int: return lib().vitx_model_seq_len(self._h)              # 0 (classifier) or 25 (ViTSTR: rows per image)
     @property
     def num_classes(self) -> int: return self.hparams.num_classes
     @property
@@ -188,6 +196,22 @@ def preprocess(img_u8: np.ndarray, img_size: int, interp: int = BICUBIC) -> np.n
     return out
 
 
+def preprocess_vitstr(img_u8: np.ndarray, img_size: int) -> np.ndarray:
+    """vit_image_preprocess of extensions/vitstr.cpp (vitstr.cpp:135-201): HWC u8 RGB -> [S,S] f32 grey in [-1, 1]."""
+    img = np.ascontiguousarray(img_u8, np.uint8); ny, nx = img.shape[:2]
+    out = np.empty((img_size, img_size), np.float32)
+    check(lib().vitx_preprocess_vitstr_u8(img.ctypes.data_as(C.POINTER(C.c_uint8)), nx, ny, img_size, out.ctypes.data_as(C.POINTER(C.c_float))), "vitx_preprocess_vitstr_u8")
+    return out
+
+
+def vitstr_decode(probs: np.ndarray):
+    """Greedy decode of one image's [25, C] probabilities (vitstr.cpp:1025-1051) -> (class ids, score)."""
+    p = np.ascontiguousarray(probs, np.float32); R, Cn = p.shape
+    ids = (C.c_int32 * R)(); n = C.c_int(); score = C.c_double()
+    check(lib().vitx_vitstr_decode(p.ctypes.data_as(C.POINTER(C.c_float)), R, Cn, ids, C.byref(n), C.byref(score)), "vitx_vitstr_decode")
+    return list(ids)[:n.value], score.value
+
+
 def preprocess_device(d_u8: int, n: int, nx: int, ny: int, img_size: int, d_out: int, interp: int = BICUBIC, stream: int = 0) -> None:
     """vit_image_preprocess on the GPU (device pointers; enqueue only)."""
     check(lib().vitx_preprocess_u8_device(d_u8, n, nx, ny, img_size, interp, d_out, stream or None), "vitx_preprocess_u8_device")
@@ -214,7 +238,8 @@ class Context:
     def forward(self, imgs_hwc: np.ndarray, want_logits: bool = False):
         """Host arrays in/out (copies + sync): [n,S,S,3] f32 -> probs [n,C] (and logits)."""
         x = np.ascontiguousarray(imgs_hwc, np.float32); n = x.shape[0]
-        probs = np.empty((n, self.model.num_classes), np.float32)
+        R = self.model.seq_len                      # ViTSTR: [n, S, S] grey in, [n, 25, C] out
+        probs = np.empty((n, self.model.num_classes) if R == 0 else (n, R, self.model.num_classes), np.float32)
         logits = np.empty_like(probs) if want_logits else None
         fp = C.POINTER(C.c_float)
         check(lib().vitx_forward(self._h, x.ctypes.data_as(fp), n, probs.ctypes.data_as(fp), logits.ctypes.data_as(fp) if want_logits else None), "vitx_forward")

@@ -60,6 +60,8 @@ struct vitx_ctx {
     vitx_hparams hp{};
     int device = 0, dtype = VITX_F16, max_batch = 0;
     int D = 0, L = 0, H = 0, C = 0, P = 0, S = 0, g = 0, N = 0, Kpe = 0, Kpe_pad = 0, C_pad = 0;
+    int Cin = 3;                         // input channels: 3 (RGB classifier) or 1 (ViTSTR, grey)
+    int R = 1;                           // probability rows per image: 1 (cls token) or 25 (ViTSTR: tokens 0..24, vitstr.cpp:864-904)
     int tm = 128, tn = 128;
     const Tuning *tune = nullptr;        // per-device launch parameters (CU count, kernel selection), immutable
     int split_override[4] = {0, 0, 0, 0};  // VITX_SPLIT, parsed at creation
@@ -251,7 +253,9 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     if (!c) return VITX_ERR_NOMEM;
     c->model = m; c->hp = hp; c->device = device; c->dtype = dtype; c->max_batch = max_batch;
     c->D = hp.hidden_size; c->L = hp.num_hidden_layers; c->H = hp.num_attention_heads; c->C = hp.num_classes; c->P = hp.patch_size; c->S = hp.img_size;
-    c->g = c->S / c->P; c->N = c->g * c->g + 1; c->Kpe = 3 * c->P * c->P; c->Kpe_pad = round_up(c->Kpe, 64);
+    c->Cin = m->in_chans; c->R = m->in_chans == 1 ? VITX_VITSTR_SEQ_LEN : 1;
+    c->g = c->S / c->P; c->N = c->g * c->g + 1; c->Kpe = c->Cin * c->P * c->P; c->Kpe_pad = round_up(c->Kpe, 64);
+    if (c->N < c->R) { set_error("vitx_ctx_create: a ViTSTR head reads %d tokens, this model has %d (img_size %d, patch_size %d)", c->R, c->N, c->S, c->P); return VITX_ERR_UNSUPPORTED; }
     c->tm = gemm_tile_m(); c->tn = gemm_tile_n();
     c->C_pad = round_up(c->C, c->tn);
     // validate against what the kernels are actually instantiated for (a context that would fail on its first forward is refused here)
@@ -313,7 +317,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     for (int i = 0; i < ns; ++i) {
         vitx_ctx::Slice &sl = c->slices[i];
         sl.cap = max_batch;     // every slice can hold the whole batch: the split point is chosen per call (split_batch)
-        const size_t Mpad = (size_t)round_up(sl.cap * c->N, c->tm), Bpad = (size_t)round_up(sl.cap, c->tm);
+        const size_t Mpad = (size_t)round_up(sl.cap * c->N, c->tm), Bpad = (size_t)round_up(sl.cap * c->R, c->tm);
         if ((rc = c->dmalloc((void **)&sl.X, Mpad * D * 4, true))) return rc;
         if ((rc = c->dmalloc(&sl.U, Mpad * D * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.QKV, Mpad * 3 * D * 2, true))) return rc;
@@ -341,9 +345,9 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         }
     }
     if (ns > 1) HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
-    if ((rc = c->dmalloc((void **)&c->img, (size_t)max_batch * c->S * c->S * 3 * 4, false))) return rc;
-    if ((rc = c->dmalloc((void **)&c->probs, (size_t)max_batch * c->C * 4, true))) return rc;
-    if ((rc = c->dmalloc((void **)&c->logits_all, (size_t)max_batch * c->C * 4, true))) return rc;
+    if ((rc = c->dmalloc((void **)&c->img, (size_t)max_batch * c->S * c->S * c->Cin * 4, false))) return rc;
+    if ((rc = c->dmalloc((void **)&c->probs, (size_t)max_batch * c->R * c->C * 4, true))) return rc;
+    if ((rc = c->dmalloc((void **)&c->logits_all, (size_t)max_batch * c->R * c->C * 4, true))) return rc;
     HIP_TRY(hipDeviceSynchronize());
     *out = c.release();
     return VITX_OK;
@@ -351,6 +355,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
 
 void vitx_ctx_free(vitx_ctx *c) { delete c; }
 int vitx_ctx_max_batch(const vitx_ctx *c) { return c ? c->max_batch : 0; }
+int vitx_ctx_out_rows(const vitx_ctx *c) { return c ? c->R : 0; }
 
 static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const void *d_imgs, int first_img, int n, void *d_probs, void *d_logits) {
     // residual-stream trace: copy X of the traced images that live in this sub-batch (stage 0 = after patch embedding, il + 1 = after layer il)
@@ -372,8 +377,8 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
 
     // patch embedding: im2col -> GEMM(+bias, +pos, token scatter) ; cls rows      (vit.cpp:747-797)
     {
-        ProfScope ps(c, st, PC_PATCHIFY, 0, (double)n * c->S * c->S * 3 * 4 + (double)Mp_real * c->Kpe_pad * eb);
-        HIP_TRY(launch_patchify(dt, (const float *)d_imgs, sl.Hbuf, n, c->S, c->P, c->Kpe_pad, Mp, st));
+        ProfScope ps(c, st, PC_PATCHIFY, 0, (double)n * c->S * c->S * c->Cin * 4 + (double)Mp_real * c->Kpe_pad * eb);
+        HIP_TRY(launch_patchify(dt, (const float *)d_imgs, sl.Hbuf, n, c->S, c->P, c->Kpe_pad, Mp, st, c->Cin));
     }
     int rc;
     if ((rc = gemm(c, tn_, st, PC_GEMM_PATCH, EPI_PATCH, sl.Hbuf, c->pe_w, c->pe_b, sl.X, c->pos, Mp, Mp_real, D, round_up(D, tn), c->Kpe_pad,
@@ -437,23 +442,25 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2]))) return rc;
         if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
-    // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D
+    // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D.  ViTSTR (vitstr.cpp:864-895) keeps the first
+    // R = 25 tokens of every image instead: output row r = image r / R, token r % R.
+    const int nR = n * c->R;
     {
-        ProfScope ps(c, st, PC_LAYERNORM, 0, (double)n * D * (4 + eb));
-        HIP_TRY(launch_layernorm(dt, sl.X, (long)N * D, c->norm_w, c->norm_b, sl.Z, D, n, D, c->hp.eps, st));
+        ProfScope ps(c, st, PC_LAYERNORM, 0, (double)nR * D * (4 + eb));
+        HIP_TRY(launch_layernorm(dt, sl.X, D, c->norm_w, c->norm_b, sl.Z, D, nR, D, c->hp.eps, st, c->R, (long)N * D));
     }
     // classifier (vit.cpp:927-928) and class softmax (vit.cpp:931-933)
     float *lg = d_logits ? (float *)d_logits : sl.logits;
     const int ldl = d_logits ? c->C : c->C_pad;
     const void *head_w = c->head_w; const QuantW *head_f = nullptr;
     if (c->head_q.blocks) {
-        if (fused_ok(c->head_q, round_up(n, tm))) head_f = &c->head_q;
+        if (fused_ok(c->head_q, round_up(nR, tm))) head_f = &c->head_q;
         else { const QuantW *todo[1] = {&c->head_q}; void *dst[1] = {sl.Wq_head}; if ((rc = expand(todo, dst, 1))) return rc; head_w = sl.Wq_head; }
     }
-    if ((rc = gemm(c, tn_, st, PC_GEMM_HEAD, EPI_BIAS_F32, sl.Z, head_w, c->head_b, lg, nullptr, round_up(n, tm), n, c->C, c->C_pad, D, D, D, ldl, 0, 4, head_f))) return rc;
+    if ((rc = gemm(c, tn_, st, PC_GEMM_HEAD, EPI_BIAS_F32, sl.Z, head_w, c->head_b, lg, nullptr, round_up(nR, tm), nR, c->C, c->C_pad, D, D, D, ldl, 0, 4, head_f))) return rc;
     {
-        ProfScope ps(c, st, PC_SOFTMAX, 0, (double)n * c->C * 8);
-        HIP_TRY(launch_softmax(dt, lg, (float *)d_probs, n, c->C, ldl, st));
+        ProfScope ps(c, st, PC_SOFTMAX, 0, (double)nR * c->C * 8);
+        HIP_TRY(launch_softmax(dt, lg, (float *)d_probs, nR, c->C, ldl, st));
     }
     return VITX_OK;
 }
@@ -519,8 +526,8 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
         vitx_ctx::Slice &sl = c->slices[i];
         hipStream_t ss = serial ? st : sl.stream;
         if (!serial) HIP_TRY(hipStreamWaitEvent(sl.stream, c->fork, 0));
-        int rc = forward_slice(c, sl, ss, (const float *)d_imgs + (size_t)off * c->S * c->S * 3, off, m[i], (float *)d_probs + (size_t)off * c->C,
-                               d_logits ? (float *)d_logits + (size_t)off * c->C : nullptr);
+        int rc = forward_slice(c, sl, ss, (const float *)d_imgs + (size_t)off * c->S * c->S * c->Cin, off, m[i], (float *)d_probs + (size_t)off * c->R * c->C,
+                               d_logits ? (float *)d_logits + (size_t)off * c->R * c->C : nullptr);
         if (rc) return rc;
         if (!serial) {
             HIP_TRY(hipEventRecord(sl.done, sl.stream));
@@ -535,12 +542,12 @@ int vitx_forward(vitx_ctx *c, const float *imgs, int n, float *probs, float *log
     if (!c || !imgs || !probs) { set_error("vitx_forward: NULL argument"); return VITX_ERR_ARG; }
     if (n <= 0 || n > c->max_batch) { set_error("vitx_forward: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    const size_t img_bytes = (size_t)n * c->S * c->S * 3 * 4;
+    const size_t img_bytes = (size_t)n * c->S * c->S * c->Cin * 4;
     HIP_TRY(hipMemcpyAsync(c->img, imgs, img_bytes, hipMemcpyHostToDevice, c->stream));
     int rc = vitx_forward_device(c, c->img, n, c->probs, logits ? c->logits_all : nullptr, c->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(probs, c->probs, (size_t)n * c->C * 4, hipMemcpyDeviceToHost, c->stream));
-    if (logits) HIP_TRY(hipMemcpyAsync(logits, c->logits_all, (size_t)n * c->C * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(probs, c->probs, (size_t)n * c->R * c->C * 4, hipMemcpyDeviceToHost, c->stream));
+    if (logits) HIP_TRY(hipMemcpyAsync(logits, c->logits_all, (size_t)n * c->R * c->C * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return VITX_OK;
 }

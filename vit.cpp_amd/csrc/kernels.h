@@ -73,11 +73,13 @@ int gemm_tile_m();   // M granularity the GEMM needs (buffer row padding)
 int gemm_tile_n();
 
 // im2col of the f32 HWC image into dtype rows [n_img*g*g][Kpad], k = c*P*P + ky*P + kx (vit.cpp:759-772)
-hipError_t launch_patchify(int dtype, const float *img, void *out, int n_img, int S, int P, int Kpad, int rows_pad, hipStream_t stream);
+// (Cin = 3: RGB classifier input; 1: the grey ViTSTR input, extensions/vitstr.cpp/vitstr.cpp:713-731)
+hipError_t launch_patchify(int dtype, const float *img, void *out, int n_img, int S, int P, int Kpad, int rows_pad, hipStream_t stream, int Cin = 3);
 // X[b*N + 0][:] = cls + pos[0]  (vit.cpp:794-797)
 hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_img, int N, int D, hipStream_t stream);
 // y[r][:] (dtype) = LN(x[r*ldx ...]) * w + b   (vit.cpp:808-812)
-hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream);
+// group > 1: input row r = x + (r / group) * gstride + (r % group) * ldx (the first `group` tokens of every image: ViTSTR head)
+hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream, int group = 1, long gstride = 0);
 // fused per-(image,head) attention  (vit.cpp:826-866)
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream);
 bool attention_supports(int N, int D, int H);     // head_dim 64, any token count

@@ -276,8 +276,8 @@ hipError_t launch_gemm_q4(int dtype, int epi, const GemmArgs &a, hipStream_t str
 // per thread; columns k >= 3*P*P and rows >= n_img*g*g are zero padding.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ img, T *__restrict__ out, int n_img, int S, int P, int Kpad, int rows_pad) {
-    const int g = S / P, tpi = g * g, K = 3 * P * P, PP = P * P;
+__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ img, T *__restrict__ out, int n_img, int S, int P, int Kpad, int rows_pad, int Cin) {
+    const int g = S / P, tpi = g * g, K = Cin * P * P, PP = P * P;
     const int chunks_per_row = Kpad / 8;
     const long total = (long)rows_pad * chunks_per_row;
     for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__
             float x = 0.0f;
             if (row < n_img * tpi && k < K) {
                 const int c = k / PP, rem = k - c * PP, ky = rem / P, kx = rem - ky * P;
-                x = img[(((size_t)b * S + (py * P + ky)) * S + (px * P + kx)) * 3 + c];
+                x = img[(((size_t)b * S + (py * P + ky)) * S + (px * P + kx)) * Cin + c];
             }
             v[j] = (T)x;
         }
@@ -298,11 +298,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__
     }
 }
 
-hipError_t launch_patchify(int dtype, const float *img, void *out, int n_img, int S, int P, int Kpad, int rows_pad, hipStream_t stream) {
+hipError_t launch_patchify(int dtype, const float *img, void *out, int n_img, int S, int P, int Kpad, int rows_pad, hipStream_t stream, int Cin) {
     const long total = (long)rows_pad * (Kpad / 8);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (dtype == DT_F16) hipLaunchKernelGGL(patchify_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, img, (_Float16 *)out, n_img, S, P, Kpad, rows_pad);
-    else hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, img, (__bf16 *)out, n_img, S, P, Kpad, rows_pad);
+    if (dtype == DT_F16) hipLaunchKernelGGL(patchify_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, img, (_Float16 *)out, n_img, S, P, Kpad, rows_pad, Cin);
+    else hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, img, (__bf16 *)out, n_img, S, P, Kpad, rows_pad, Cin);
     return hipGetLastError();
 }
 
@@ -323,12 +323,14 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_i
 // ------------------------------------------------------------------------------------------------
 template <typename T, int VEC, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ w, const float *__restrict__ b,
-                                                        T *__restrict__ y, long ldy, int M, float eps) {
+                                                        T *__restrict__ y, long ldy, int M, float eps, int group, long gstride) {
     constexpr int D = 64 * VEC * NV;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float *xr = x + (size_t)row * ldx;
+    // input row: group == 1 -> row * ldx; otherwise rows come in groups (row / group) * gstride + (row % group) * ldx
+    // (the first `group` tokens of every image: the ViTSTR head, vitstr.cpp:864-883)
+    const float *xr = group == 1 ? x + (size_t)row * ldx : x + (size_t)(row / group) * gstride + (size_t)(row % group) * ldx;
     float v[NV][VEC];
     float sum = 0.0f;
 #pragma unroll
@@ -367,10 +369,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }
 
 template <typename T>
-static hipError_t launch_layernorm_t(const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream) {
+static hipError_t launch_layernorm_t(const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream, int group, long gstride) {
     const dim3 grid((M + 3) / 4), blk(256);
 #define VITX_LN_CASE(DD, VEC, NV) \
-    case DD: hipLaunchKernelGGL((layernorm_kernel<T, VEC, NV>), grid, blk, 0, stream, x, ldx, w, b, (T *)y, ldy, M, eps); break;
+    case DD: hipLaunchKernelGGL((layernorm_kernel<T, VEC, NV>), grid, blk, 0, stream, x, ldx, w, b, (T *)y, ldy, M, eps, group, gstride); break;
     switch (D) {
         VITX_LN_CASE(64, 1, 1) VITX_LN_CASE(128, 2, 1) VITX_LN_CASE(192, 1, 3) VITX_LN_CASE(256, 4, 1) VITX_LN_CASE(384, 2, 3)
         VITX_LN_CASE(512, 4, 2) VITX_LN_CASE(768, 4, 3) VITX_LN_CASE(1024, 4, 4) VITX_LN_CASE(1280, 4, 5) VITX_LN_CASE(1536, 4, 6)
@@ -382,8 +384,9 @@ static hipError_t launch_layernorm_t(const float *x, long ldx, const float *w, c
 bool layernorm_supports(int D) {
     switch (D) { case 64: case 128: case 192: case 256: case 384: case 512: case 768: case 1024: case 1280: case 1536: return true; default: return false; }
 }
-hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream) {
-    return dtype == DT_F16 ? launch_layernorm_t<_Float16>(x, ldx, w, b, y, ldy, M, D, eps, stream) : launch_layernorm_t<__bf16>(x, ldx, w, b, y, ldy, M, D, eps, stream);
+hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream, int group, long gstride) {
+    if (group < 1) return hipErrorInvalidValue;
+    return dtype == DT_F16 ? launch_layernorm_t<_Float16>(x, ldx, w, b, y, ldy, M, D, eps, stream, group, gstride) : launch_layernorm_t<__bf16>(x, ldx, w, b, y, ldy, M, D, eps, stream, group, gstride);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -157,7 +157,9 @@ static int load_impl(const char *path, vitx_model &m) {
         auto it = expect.find(t.name);
         if (it == expect.end()) { set_error("vitx_model_load: unknown tensor '%s' in model file", t.name.c_str()); return VITX_ERR_FORMAT; }
         if (m.index.count(t.name)) { set_error("vitx_model_load: duplicate tensor '%s'", t.name.c_str()); return VITX_ERR_FORMAT; }
-        const Expect &ex = it->second;
+        Expect ex = it->second;
+        // ViTSTR files (extensions/vitstr.cpp/vitstr.cpp:482) carry a ONE-channel patch kernel [P, P, 1, D]: same format otherwise
+        if (t.name == "patch_embed.proj.weight" && t.ne[2] == 1 && t.ne[0] == ex.ne[0] && t.ne[1] == ex.ne[1] && t.ne[3] == ex.ne[3]) { ex.ne[2] = 1; m.in_chans = 1; }
         const int64_t want = ex.ne[0] * ex.ne[1] * ex.ne[2] * ex.ne[3];
         if (t.nelements() != want) { set_error("vitx_model_load: tensor '%s' has wrong size in model file: got %lld, expected %lld", t.name.c_str(), (long long)t.nelements(), (long long)want); return VITX_ERR_FORMAT; }
         if (t.ne[0] != ex.ne[0] || t.ne[1] != ex.ne[1] || t.ne[2] != ex.ne[2] || t.ne[3] != ex.ne[3]) {
@@ -213,6 +215,8 @@ int vitx_model_hparams(const vitx_model *m, vitx_hparams *out) {
     *out = m->hp; return VITX_OK;
 }
 int vitx_model_num_labels(const vitx_model *m) { return m ? (int)m->id2label.size() : 0; }
+int vitx_model_in_channels(const vitx_model *m) { return m ? m->in_chans : 0; }
+int vitx_model_seq_len(const vitx_model *m) { return (m && m->in_chans == 1) ? VITX_VITSTR_SEQ_LEN : 0; }
 const char *vitx_model_label(const vitx_model *m, int id) {
     if (!m) return nullptr;
     auto it = m->id2label.find(id);

@@ -96,3 +96,50 @@ extern "C" int vitx_preprocess_u8(const uint8_t *hwc, int nx, int ny, int img_si
     for (auto &t : th) t.join();
     return VITX_OK;
 }
+
+// ---- ViTSTR (extensions/vitstr.cpp) ------------------------------------------------------------------------------------
+// vit_image_preprocess of the scene-text extension (vitstr.cpp:135-201): RGB -> grey with PIL's weights evaluated in double and
+// TRUNCATED to u8 (:128-132), direct resize by (nx / S, ny / S) with a 2x2 linear blend anchored at the truncated source
+// coordinate (clamped so that the +1 neighbour exists), then (v / 255 - 0.5) * 2.  The "padding" loops of the reference run from
+// res.nx == S and are no-ops.  Output: ONE channel, [S][S] f32.
+extern "C" int vitx_preprocess_vitstr_u8(const uint8_t *hwc, int nx, int ny, int img_size, float *out) {
+    if (!hwc || !out || nx <= 0 || ny <= 0 || img_size <= 0) { vitx::set_error("vitx_preprocess_vitstr_u8: invalid argument"); return VITX_ERR_ARG; }
+    // the reference reads pixel (x + 1, y + 1) unconditionally: a 1-pixel-wide or 1-pixel-high image is outside its domain
+    if (nx < 2 || ny < 2) { vitx::set_error("vitx_preprocess_vitstr_u8: image must be at least 2 x 2 (got %d x %d)", nx, ny); return VITX_ERR_ARG; }
+    const int S = img_size;
+    std::vector<uint8_t> grey((size_t)nx * ny);
+    for (size_t i = 0; i < (size_t)nx * ny; ++i) grey[i] = (uint8_t)(0.299 * hwc[3 * i] + 0.587 * hwc[3 * i + 1] + 0.114 * hwc[3 * i + 2]);
+    const float xs = (float)nx / S, ys = (float)ny / S;
+    for (int y = 0; y < S; ++y) {
+        for (int x = 0; x < S; ++x) {
+            const float gx = x * xs, gy = y * ys;
+            const int gxi = (int)gx, gyi = (int)gy;
+            const float u = gx - gxi, v = gy - gyi;
+            const int px0 = clampi(gxi, 0, nx - 2), py0 = clampi(gyi, 0, ny - 2), px1 = px0 + 1, py1 = py0 + 1;
+            float val = (1 - u) * (1 - v) * grey[(size_t)py0 * nx + px0] + u * (1 - v) * grey[(size_t)py0 * nx + px1] +
+                        (1 - u) * v * grey[(size_t)py1 * nx + px0] + u * v * grey[(size_t)py1 * nx + px1];
+            val = (val / 255.0f - 0.5f) * 2.0f;
+            out[(size_t)y * S + x] = val;
+        }
+    }
+    return VITX_OK;
+}
+
+// The greedy decode of the extension's vit_predict (vitstr.cpp:1025-1051): positions 1 .. seq_len - 1 (position 0 is the [GO] slot),
+// arg-max class per position (first maximum wins, strict '>'), stop at class 1 = "[s]"; the score is the product of the maxima of
+// the characters emitted.  ids receives the class of every emitted character.
+extern "C" int vitx_vitstr_decode(const float *probs, int seq_len, int num_classes, int32_t *ids, int *n_ids, double *score) {
+    if (!probs || !ids || !n_ids || seq_len <= 0 || num_classes <= 0) { vitx::set_error("vitx_vitstr_decode: invalid argument"); return VITX_ERR_ARG; }
+    double conf = 1.0; int n = 0;
+    for (int col = 1; col < seq_len; ++col) {
+        const float *p = probs + (size_t)col * num_classes;
+        int best = 0; float best_v = p[0];
+        for (int row = 1; row < num_classes; ++row) if (p[row] > best_v) { best_v = p[row]; best = row; }
+        if (best == 1) break;
+        conf *= best_v;
+        ids[n++] = best;
+    }
+    *n_ids = n;
+    if (score) *score = conf;
+    return VITX_OK;
+}

@@ -26,7 +26,7 @@ struct vitx_group {
     std::vector<ncclComm_t> comm;
     std::vector<hipStream_t> stream;
     std::vector<float *> d_img, d_probs, d_all;     // per device: shard images, shard probabilities (padded to n_max), gathered [ndev][n_max][C]
-    int max_per_dev = 0, C = 0, S = 0;
+    int max_per_dev = 0, C = 0, S = 0, Cin = 3;      // C = probability floats per image
     ~vitx_group() {
         for (size_t i = 0; i < devices.size(); ++i) {
             (void)hipSetDevice(devices[i]);
@@ -53,8 +53,9 @@ int vitx_group_create(const vitx_model *m, const int *devices, int n_devices, in
     g->devices.assign(devices, devices + n_devices);
     g->ctx.assign(n_devices, nullptr); g->comm.assign(n_devices, nullptr); g->stream.assign(n_devices, nullptr);
     g->d_img.assign(n_devices, nullptr); g->d_probs.assign(n_devices, nullptr); g->d_all.assign(n_devices, nullptr);
-    g->max_per_dev = max_batch_per_device; g->C = m->hp.num_classes; g->S = m->hp.img_size;
-    const size_t img_floats = (size_t)g->S * g->S * 3;
+    // per image: in_chans planes in, out_rows x num_classes probabilities out (a ViTSTR file: 1 grey plane, 25 rows)
+    g->max_per_dev = max_batch_per_device; g->C = m->hp.num_classes * (vitx_model_seq_len(m) ? vitx_model_seq_len(m) : 1); g->S = m->hp.img_size; g->Cin = m->in_chans;
+    const size_t img_floats = (size_t)g->S * g->S * g->Cin;
     for (int i = 0; i < n_devices; ++i) {
         int rc = vitx_ctx_create(m, devices[i], max_batch_per_device, dtype, &g->ctx[i]);      // replicated weights, one context per GPU
         if (rc != VITX_OK) return rc;
@@ -87,7 +88,7 @@ int vitx_group_forward(vitx_group *g, const float *imgs_hwc, int n, float *probs
     const int ndev = (int)g->devices.size();
     const int n_max = (n + ndev - 1) / ndev;
     if (n_max > g->max_per_dev) { set_error("vitx_group_forward: %d images over %d GPUs exceeds %d per GPU", n, ndev, g->max_per_dev); return VITX_ERR_ARG; }
-    const size_t img_floats = (size_t)g->S * g->S * 3;
+    const size_t img_floats = (size_t)g->S * g->S * g->Cin;
     const int C = g->C;
     std::vector<int> rc(ndev, VITX_OK);
     std::vector<std::string> err(ndev);

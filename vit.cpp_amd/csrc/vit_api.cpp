@@ -72,6 +72,7 @@ int vit_predict_batch(const vit_model &model, vit_state &state, const image_f32 
                       std::vector<std::vector<std::pair<float, int>>> &predictions, bool print) {
     predictions.clear();
     if (!model.handle || !imgs || n <= 0) { fprintf(stderr, "%s: invalid argument\n", __func__); return 1; }
+    if (vitx_model_seq_len(model.handle) > 0) { fprintf(stderr, "%s: this is a ViTSTR model (one-channel patch kernel): use vitstr_predict\n", __func__); return 1; }
     const int S = model.hparams.img_size, C = model.hparams.num_classes;
     for (int i = 0; i < n; ++i)
         if (imgs[i].nx != S || imgs[i].ny != S || imgs[i].data.size() != (size_t)3 * S * S) {      // GGML_ASSERT at vit.cpp:757
@@ -103,6 +104,39 @@ int vit_predict_batch(const vit_model &model, vit_state &state, const image_f32 
                 printf(" > %s : %.2f\n", model.hparams.id2label.at(p[i].second).c_str(), p[i].first);
         }
     }
+    return 0;
+}
+
+// extensions/vitstr.cpp/vitstr.cpp:135-201
+bool vitstr_image_preprocess(const image_u8 &img, image_f32 &res, const vit_hparams &params) {
+    const int S = params.n_img_size();
+    res.nx = S; res.ny = S;
+    res.data.resize((size_t)S * S);
+    return vitx_preprocess_vitstr_u8(img.data.data(), img.nx, img.ny, S, res.data.data()) == VITX_OK;
+}
+
+// extensions/vitstr.cpp/vitstr.cpp:970-1061 -- 0 ok / 1 failure
+int vitstr_predict(const vit_model &model, vit_state &state, const image_f32 img1, const vit_params &params, std::string &text, double &score) {
+    (void)params;
+    text.clear(); score = 0.0;
+    if (!model.handle) { fprintf(stderr, "%s: invalid argument\n", __func__); return 1; }
+    const int R = vitx_model_seq_len(model.handle), S = model.hparams.img_size, C = model.hparams.num_classes;
+    if (R <= 0) { fprintf(stderr, "%s: not a ViTSTR model (the patch kernel has 3 input channels): use vit_predict\n", __func__); return 1; }
+    if (img1.nx != S || img1.ny != S || img1.data.size() != (size_t)S * S) { fprintf(stderr, "%s: image is %dx%d, model expects %dx%d grey\n", __func__, img1.nx, img1.ny, S, S); abort(); }
+    if (ensure_ctx(model, state, 1) != VITX_OK) { fprintf(stderr, "%s: failed to encode image: %s\n", __func__, vitx_last_error()); return 1; }
+    state.prediction.resize((size_t)R * C);
+    if (vitx_forward(state.ctx, img1.data.data(), 1, state.prediction.data(), nullptr) != VITX_OK) {
+        fprintf(stderr, "%s: failed to encode image: %s\n", __func__, vitx_last_error());
+        return 1;
+    }
+    std::vector<int32_t> ids((size_t)R);
+    int n_ids = 0;
+    if (vitx_vitstr_decode(state.prediction.data(), R, C, ids.data(), &n_ids, &score) != VITX_OK) return 1;
+    printf("------------------ \n");                                              // vitstr.cpp:1024
+    for (int i = 0; i < n_ids; ++i) { const std::string &ch = model.hparams.id2label.at(ids[i]); printf("%s", ch.c_str()); text += ch; }   // :1050
+    printf("\n");
+    printf("score : %.2f \n", score);
+    printf("------------------ \n");
     return 0;
 }
 

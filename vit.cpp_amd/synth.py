@@ -27,7 +27,14 @@ CONFIGS = {
     "vit_base_patch16_224": (768, 12, 12, 1000, 16, 224),
     "vit_large_patch16_224": (1024, 24, 16, 1000, 16, 224),
     "vit_large_patch16_384": (1024, 24, 16, 1000, 16, 384),
+    # ViTSTR (extensions/vitstr.cpp): the same encoder on ONE grey channel; the head reads the first 25 tokens (vitstr.cpp:864-904)
+    "vitstr_micro_patch16_64": (128, 2, 2, 96, 16, 64),    # test-only toy (N = 17 < 25 is NOT usable for the sequence head: see vitstr_small)
+    "vitstr_tiny_patch16_224": (192, 12, 3, 96, 16, 224),
 }
+IN_CHANS = {"vitstr_micro_patch16_64": 1, "vitstr_tiny_patch16_224": 1}     # everything else: 3 (RGB)
+VITSTR_SEQ_LEN = 25
+# ViTSTR's character set (vitstr's TokenLabelConverter): [GO], [s], then the 94 printable ASCII characters
+VITSTR_LABELS = {0: "[GO]", 1: "[s]", **{i + 2: chr(33 + i) for i in range(94)}}
 
 
 def hparams_for(name: str, ftype: int = 1) -> HParams:
@@ -44,7 +51,7 @@ def gflop_per_image(hp: HParams) -> float:
     return 2.0 * (g * g * 3 * P * P * D + L * per_layer + D * C) / 1e9
 
 
-def make_weights(hp: HParams, seed: int = 1234, head_scale: float = 8.0) -> Dict[str, np.ndarray]:
+def make_weights(hp: HParams, seed: int = 1234, head_scale: float = 8.0, in_chans: int = 3) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     D, L, C, P = hp.hidden_size, hp.num_hidden_layers, hp.num_classes, hp.patch_size
     N = hp.n_tokens
@@ -58,7 +65,7 @@ def make_weights(hp: HParams, seed: int = 1234, head_scale: float = 8.0) -> Dict
     t: Dict[str, np.ndarray] = {}
     t["cls_token"] = mat(1, 1, D)
     t["pos_embed"] = mat(1, N, D)
-    t["patch_embed.proj.weight"] = mat(D, 3, P, P)
+    t["patch_embed.proj.weight"] = mat(D, in_chans, P, P)
     t["patch_embed.proj.bias"] = vec(D)
     for i in range(L):
         p = f"blocks.{i}."
@@ -76,7 +83,8 @@ def make_weights(hp: HParams, seed: int = 1234, head_scale: float = 8.0) -> Dict
 
 def write_synthetic(path: str, name: str, ftype: int = 1, seed: int = 1234, head_scale: float = 8.0) -> HParams:
     hp = hparams_for(name, ftype)
-    write_model(path, hp, make_weights(hp, seed, head_scale), ftype=ftype)
+    ic = IN_CHANS.get(name, 3)
+    write_model(path, hp, make_weights(hp, seed, head_scale, in_chans=ic), ftype=ftype, id2label=dict(VITSTR_LABELS) if ic == 1 else None)
     return hp
 
 

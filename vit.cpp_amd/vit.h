@@ -82,5 +82,13 @@ int vit_predict(const vit_model &model, vit_state &state, const image_f32 img1, 
                 std::vector<std::pair<float, int>> &predictions);                                      // vit.h:122
 int vit_predict_batch(const vit_model &model, vit_state &state, const image_f32 *imgs, int n, const vit_params &params,
                       std::vector<std::vector<std::pair<float, int>>> &predictions, bool print = false);
+// ---- the ViTSTR scene-text extension (extensions/vitstr.cpp).  It is a separate program in the reference that re-uses the names
+// vit_image_preprocess / vit_predict with different bodies (vitstr.h:115-119); here both programs live in one library, so the
+// extension's two functions carry a vitstr_ prefix.  vit_model_load is shared: a file whose patch kernel has ONE input channel is
+// a ViTSTR model (vitstr.cpp:482).
+bool vitstr_image_preprocess(const image_u8 &img, image_f32 &res, const vit_hparams &params);         // vitstr.cpp:135-201: grey, [img_size][img_size]
+// vitstr.cpp:970-1061: forward + greedy decode; prints the text and "score : x.xx" framed by dashed lines exactly like the
+// extension, and also returns them.  state.prediction = [25][num_classes] probabilities.
+int vitstr_predict(const vit_model &model, vit_state &state, const image_f32 img1, const vit_params &params, std::string &text, double &score);
 void print_usage(int argc, char **argv, const vit_params &params);                                     // vit.h:123
 bool vit_params_parse(int argc, char **argv, vit_params &params);                                      // vit.h:124
