@@ -422,3 +422,43 @@ def test_group_two_devices_match_one(pkg, binding, torch_gpu):
     for n in (13, 2, 1):                                     # 13 = 7 + 6 ragged shards; 1 = second device idle
         assert np.array_equal(grp.forward(imgs[:n]), want[:n])
     grp.close(); model.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LayerNorm fused into the residual GEMMs (r02c)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype_name", ["f16", "bf16"])
+@pytest.mark.parametrize("name,n", [("vit_base_patch16_224", 37), ("vit_base_patch16_224", 256), ("vit_large_patch16_384", 9)])
+def test_layernorm_fused_into_residual_gemms_is_bit_identical(pkg, binding, torch_gpu, name, n, dtype_name):
+    """proj / fc2 on the ping-pong kernel normalise every 256-row block of the residual stream as soon as its last column tile is
+    stored (gemm_pp.hip, FLAGS 32768: cross-workgroup ticket + agent-scope acquire), replacing 2 of the 2 LayerNorm launches per layer.
+    Same sums in the same order as layernorm_kernel -> the whole forward is BIT-identical to VITX_LN_FUSE=0, with ragged last row
+    blocks (37 x 197 and 9 x 577 rows are not multiples of 256), two sub-batch streams (256 images) and both operand types; repeated
+    forwards on one context stay identical (the arrival counters reset themselves)."""
+    import os
+    torch = torch_gpu
+    dt = binding.F16 if dtype_name == "f16" else binding.BF16
+    path = pkg.synth.cached_synthetic(name, head_scale=8.0)
+    hp = pkg.synth.hparams_for(name)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    imgs = torch.randn((n, hp.img_size, hp.img_size, 3), device="cuda", generator=g)
+    outs = {}
+    for fuse in ("0", "1"):                 # the fused path is opt-in (it is slower: profiles/r02c/layernorm_fusion.txt)
+        os.environ["VITX_LN_FUSE"] = fuse
+        try:
+            # VITX_LN_FUSE is read when the context is created
+            model = binding.Model(path)
+            ctx = binding.Context(model, device=0, max_batch=n, dtype=dt)
+        finally:
+            os.environ.pop("VITX_LN_FUSE", None)
+        res = []
+        for rep in range(3):
+            probs = torch.empty((n, hp.num_classes), device="cuda"); logits = torch.empty_like(probs)
+            ctx.forward_device(imgs.data_ptr(), n, probs.data_ptr(), logits.data_ptr(), 0)
+            ctx.synchronize()
+            res.append(logits.clone())
+        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+        outs[fuse] = res[0]
+        ctx.close(); model.close()
+    assert torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["0"], outs["1"])

@@ -80,6 +80,10 @@ struct vitx_ctx {
     // on ViT-B (profiles/r02c_quant.txt) the 128x128-tile fused kernel loses to "expand the layer just in time, then the skinny ring
     // kernels" at every batch size (batch 1: 1.75 vs 1.06 ms, batch 8: 2.15 vs 1.33 ms), so it is an option, not the default.
     int q4_fused_rows = 0;
+    // VITX_LN_FUSE=1 (read at context creation): norm2 / the next layer's norm1 ride in the proj / fc2 GEMMs on the ping-pong kernel
+    // (gemm_pp.hip FLAGS 32768).  Bit-identical and tested, but OFF by default: measured 13.3 vs 10.5 ms per ViT-B batch-256 forward
+    // (profiles/r02c/layernorm_fusion.txt) -- the hand-off itself is free, the row pass of a 256-row block on ONE workgroup is not.
+    bool ln_fuse = false;
     size_t weight_bytes = 0;             // device bytes held by weight matrices (vitx_ctx_weight_bytes)
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
@@ -91,6 +95,7 @@ struct vitx_ctx {
         void *QKV = nullptr;         // [Mpad][3D]
         void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
         void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
+        int *ln_cnt = nullptr;       // [Mpad / 256] arrival counters of the LayerNorm fused into the proj / fc2 GEMMs (gemm_pp.hip)
         void *Wq[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};   // just-in-time expansion of the current layer's quantised matrices
         void *Wq_head = nullptr;
         float *logits = nullptr;     // [Bpad][C_pad]
@@ -219,10 +224,18 @@ struct ProfScope {
 
 // `fused` != nullptr: W is that q4_0 matrix and the GEMM expands the blocks in its own LDS-fill path (small batches).
 int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
-         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr) {
+         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr,
+         const GemmArgs *ln = nullptr /* ln_out / ln_cnt / ln_w / ln_b / ln_eps: the LayerNorm that follows this GEMM */, bool *ln_fused = nullptr) {
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
     a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
+    if (ln_fused) *ln_fused = false;
+    // the LayerNorm of the output rows rides in the GEMM when the ping-pong kernel takes it in one launch (never while profiling: the
+    // per-kernel event times are meant to be comparable across builds, and a fused launch would be booked under the GEMM class alone)
+    if (ln && ln_fused && !fused && epi == EPI_BIAS_RESID && c->ln_fuse && !c->prof_on && gemm_can_fuse_layernorm(tune, a)) {
+        a.ln_out = ln->ln_out; a.ln_cnt = ln->ln_cnt; a.ln_w = ln->ln_w; a.ln_b = ln->ln_b; a.ln_eps = ln->ln_eps;
+        *ln_fused = true;
+    }
     double bytes = (double)M_real * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
     ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
@@ -273,6 +286,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     c->slices_serial = getenv("VITX_SLICES_SERIAL") != nullptr;
     c->quant_on_device = getenv("VITX_QUANT_HOST") == nullptr;
     if (const char *e = getenv("VITX_Q4_FUSED_ROWS")) c->q4_fused_rows = atoi(e);
+    if (const char *e = getenv("VITX_LN_FUSE")) c->ln_fuse = atoi(e) != 0;
     if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);     // for rocprofv3 runs that should match the profiled steps
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
@@ -324,6 +338,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
         if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
+        if ((rc = c->dmalloc((void **)&sl.ln_cnt, (Mpad / 256 + 1) * sizeof(int), true))) return rc;
         // expansion scratch for quantised matrices: one buffer per matrix kind, shared by all layers (the largest layer decides)
         for (int k = 0; k < W_PER_LAYER; ++k) {
             size_t need = 0;
@@ -407,6 +422,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         }
         return VITX_OK;
     };
+    bool ln1_done = false;                           // norm1 of the coming layer was produced by the previous layer's fc2 GEMM
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
         const void *Wl[W_PER_LAYER] = {w.qkv_w, w.proj_w, w.fc1_w, w.fc2_w};
@@ -421,7 +437,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             }
             if (any && (rc = expand(todo, sl.Wq, W_PER_LAYER))) return rc;
         }
-        {   // norm1 (vit.cpp:808-812)
+        if (!ln1_done) {   // norm1 (vit.cpp:808-812)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
             if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
@@ -432,14 +448,22 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             if (!(c->skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873)
-        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, Wl[W_PROJ], w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4, Fl[W_PROJ]))) return rc;
-        {   // norm2 (vit.cpp:881-885)
+        // norm2 (vit.cpp:881-885) rides in the GEMM where it can: the workgroup that completes a 256-row block of X normalises it into U
+        // (U is also this GEMM's A operand -- a row block's rows are only overwritten after all of its column tiles have been read)
+        GemmArgs ln2{}; ln2.ln_out = sl.U; ln2.ln_cnt = sl.ln_cnt; ln2.ln_w = w.ln2_w; ln2.ln_b = w.ln2_b; ln2.ln_eps = c->hp.eps;
+        bool ln2_done = false;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, Wl[W_PROJ], w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4, Fl[W_PROJ], &ln2, &ln2_done))) return rc;
+        if (!ln2_done) {   // norm2 (vit.cpp:881-885)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
             if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // MLP (vit.cpp:889-900)
         if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1]))) return rc;
-        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2]))) return rc;
+        // the NEXT layer's norm1 rides in fc2 the same way (the last layer is followed by the cls-row norm instead)
+        GemmArgs ln1{}; ln1_done = false;
+        if (il + 1 < c->L) { const LayerW &nx = c->layers[il + 1]; ln1.ln_out = sl.U; ln1.ln_cnt = sl.ln_cnt; ln1.ln_w = nx.ln1_w; ln1.ln_b = nx.ln1_b; ln1.ln_eps = c->hp.eps; }
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2],
+                       il + 1 < c->L ? &ln1 : nullptr, &ln1_done))) return rc;
         if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D.  ViTSTR (vitstr.cpp:864-895) keeps the first

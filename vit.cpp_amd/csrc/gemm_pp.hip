@@ -127,13 +127,14 @@ __device__ __forceinline__ void pp_lds_fence() { asm volatile("" ::: "memory"); 
 // 16-byte buffer store followed by the wait states hipcc does not insert: with an SGPR soffset LLVM's hazard recognizer assumes
 // "store of more than 64 bits -> VALU overwrite of its data registers" cannot happen, but on gfx950 the very next VALU write DID
 // corrupt the stored dwords (r02: 0.7 % of the f32-epilogue outputs, 1 % of the GELU outputs, always the same lanes).
+template <int AUX = 0>      // AUX 16 = sc1 (write-through): the tile is handed to another workgroup inside the launch
 __device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(d, ro, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, ro, voff, soff, AUX);
     __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
 }
 template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
 
-template <typename T, int EPI, bool NOSTORE = false>
+template <typename T, int EPI, bool NOSTORE = false, int AUX = 0>
 __device__ __forceinline__ void pp_epilogue_full(f32x16 (&acc)[4][2], __amdgpu_buffer_rsrc_t ro, char *patch /* wave-private 4 KiB; its first 256 B hold the bias of the wave's 64 columns */,
                                                   int voff /* this lane's byte offset in row layout */, int soff /* tile origin */, int soff8 /* 8 rows */, int lane) {
     const int l31 = lane & 31, hh = lane >> 5;
@@ -206,7 +207,61 @@ __device__ __forceinline__ void pp_epilogue_full(f32x16 (&acc)[4][2], __amdgpu_b
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
-                pp_store_b128(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
+                pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
+            }
+        }
+    }
+}
+
+// LayerNorm of rows m0 .. m0 + nrows - 1 of the f32 matrix the GEMM just completed (g.out, row length g.N = 256 * NV floats), written
+// as operand-type rows to g.ln_out: the arithmetic of layernorm_kernel (kernels.hip) statement for statement -- per lane 4 * NV values
+// (float4 i at element (i * 64 + lane) * 4), sum over i then j, xor-shuffle tree, mean, centred sum of squares, same tree,
+// 1 / sqrt(var + eps), ((x - mean) * scale) * w + b, one rounding -- so the fused path is bit-identical to the stand-alone kernel
+// (/root/reference/vit.cpp:808-812, 881-885).  One wave per row, four rows in flight per wave.
+template <typename T>
+__device__ __forceinline__ void pp_layernorm_rows(const GemmArgs &g, int m0, int nrows, int wave, int lane) {
+    const int D = g.N, NV = D >> 8;
+    const float *X = (const float *)g.out;
+    T *U = (T *)g.ln_out;
+    for (int r0 = wave * 4; r0 < nrows; r0 += 32) {
+        float v[4][6][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = min(r0 + q, nrows - 1);                  // rows past the end re-read the last row and are not stored
+            const float *xr = X + (size_t)(m0 + r) * g.ldo;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (i < NV) { const f32x4 t = *(const f32x4 *)(xr + (i * 64 + lane) * 4); v[q][i][0] = t[0]; v[q][i][1] = t[1]; v[q][i][2] = t[2]; v[q][i][3] = t[3]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (i < NV) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += v[q][i][j];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float)D;
+            float sum2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (i < NV) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[q][i][j] -= mean; sum2 += v[q][i][j] * v[q][i][j]; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o);
+            const float scale = 1.0f / sqrtf(sum2 / (float)D + g.ln_eps);
+            if (r0 + q < nrows) {
+                T *yr = U + (size_t)(m0 + r0 + q) * D;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (i < NV) {
+                    const int idx = (i * 64 + lane) * 4;
+                    typename Elem<T>::v4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { float t = v[q][i][j] * scale; t = t * g.ln_w[idx + j]; o[j] = (T)(t + g.ln_b[idx + j]); }
+                    *(typename Elem<T>::v4 *)(yr + idx) = o;
+                }
             }
         }
     }
@@ -465,6 +520,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         }
         if constexpr ((FLAGS & 16) != 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" :: "v"(fa[ii][ks]), "v"(fb[ii][ks])); } }
         const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
+        // The second wave row runs one barrier behind, so its last K-loop barrier would only be released by the first row's first
+        // barrier of the NEXT tile -- i.e. after the first row's epilogue, and the two rows' epilogues would run one after the other.
+        // Aligning the rows here (and restoring the offset after the epilogue) lets both epilogues run at the same time: forward
+        // 10.82 -> 10.75 ms, fc1 +4 % (r02c; FLAGS 8192 = the unaligned r02a behaviour, kept for A/B).
+        if constexpr ((FLAGS & 8192) == 0) { if (!(FLAGS & 2) && wr == 0) pp_barrier(); }
         if constexpr ((FLAGS & 2048) != 0) {
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
         } else if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
@@ -473,13 +533,37 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             const int voff = ((wr * 128 + (lane >> 3)) * g.ldo + wc * 64) * esz + (lane & 7) * 16;
             // readfirstlane: the tile origin comes out of an integer division done on the VALU; without it hipcc wraps every
             // buffer op in a waterfall loop over the (uniform) SGPR offset
-            pp_epilogue_full<T, EPI, (FLAGS & 16384) != 0>(acc, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
+            pp_epilogue_full<T, EPI, (FLAGS & 16384) != 0, (FLAGS & 32768) ? 16 : 0>(acc, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
             relaxed = true;
         } else {
             const int row0 = m0 + wr * 128 + l31, ncol = n0 + wc * 64;
             if (full) pp_epilogue<T, EPI, true>(g, acc, row0, ncol, hh);
             else pp_epilogue<T, EPI, false>(g, acc, row0, ncol, hh);
         }
+        if constexpr ((FLAGS & 32768) != 0) {
+            // ---- LayerNorm of row blocks whose last column tile just finished (EPI_BIAS_RESID, N == ldo == hidden size).
+            // The wave rows are aligned here.  Hand-off between workgroups (cdna_hip_programming.md Guideline 16, fan-in form): the tile's
+            // X stores were write-through (sc1) -> every wave drains them -> barrier -> ONE lane takes a ticket (relaxed, agent scope);
+            // the workgroup that draws the last ticket of the row block acquires (drops its stale L1/L2 lines) and normalises the
+            // block's rows exactly as layernorm_kernel does (same sums in the same order): bit-identical U.
+            if (!(g.dbg & 128)) {
+            pp_wait_vmcnt<0>();
+            pp_barrier();
+            volatile int *flag = (volatile int *)(smem + LDS + 2048);       // wave 0's patch, beyond the bias bytes
+            if (tid == 0) {
+                if (!full) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // ragged tile: plain stores
+                int *cnt = g.ln_cnt + m0 / BM;
+                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == ntn - 1;
+                if (last) { __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+                *flag = last;
+            }
+            pp_barrier();
+            if (*flag && !(g.dbg & 64)) pp_layernorm_rows<T>(g, m0, min(BM, g.M_real - m0), wave, lane);
+            relaxed = false;                       // everything was drained above
+            }
+        }
+        if constexpr ((FLAGS & 8192) == 0) { if (!(FLAGS & 2) && wr == 1) pp_barrier(); }
     }
     if (!(FLAGS & 2) && wr == 0) pp_barrier();
     pp_wait_vmcnt<0>();                             // the trailing (unused) stages must land before the LDS allocation is released
@@ -510,6 +594,20 @@ static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream
 }
 template <typename T>
 static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags, bool prepare) {
+    if (flags == 32768) {      // LayerNorm of finished row blocks fused into the residual GEMM
+        if (epi != EPI_BIAS_RESID || !a.ln_out || !a.ln_cnt || !a.ln_w || !a.ln_b || a.N != a.ldo || a.N % 256 || a.N > 1536) return hipErrorInvalidValue;
+        return launch_pp_inst<T, EPI_BIAS_RESID, 32768>(a, n_cu, stream, prepare);
+    }
+    if (flags == 8192) {       // wave rows NOT aligned at the epilogue (the r02a behaviour, for A/B): every epilogue
+        switch (epi) {
+        case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 8192>(a, n_cu, stream, prepare);
+        case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 8192>(a, n_cu, stream, prepare);
+        case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 8192>(a, n_cu, stream, prepare);
+        case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 8192>(a, n_cu, stream, prepare);
+        case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 8192>(a, n_cu, stream, prepare);
+        default: return hipErrorInvalidValue;
+        }
+    }
     if (flags == 4096) {       // two-burst schedule: every epilogue
         switch (epi) {
         case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 4096>(a, n_cu, stream, prepare);

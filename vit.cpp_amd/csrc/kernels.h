@@ -31,6 +31,10 @@ struct GemmArgs {
     // scales [N_pad][K/32]; both planes are the file's block_q4_0 fields re-laid out, 4.5 bits per weight
     const uint16_t *Wscale;
     int group_m;  // ping-pong kernel: m-tiles per raster group (0 = the default, 8); VITX_GROUP_M / LAB_GROUP_M experiments
+    // EPI_BIAS_RESID on the ping-pong kernel with N == ldo (whole rows): when ln_out is set, the workgroup that finishes the LAST
+    // column tile of a 256-row block also normalises those rows (LayerNorm, vit.cpp:808-812 / 881-885) into ln_out [M][N] of the
+    // operand type.  ln_cnt: one zeroed int per row block (the last arriver resets it).
+    void *ln_out; int *ln_cnt; const float *ln_w, *ln_b; float ln_eps;
 };
 
 // ---- block-quantised weights resident in HBM (quant.hip) -------------------------------------------
@@ -58,6 +62,8 @@ struct Tuning {
     int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
     int gemm_split = 0;      // VITX_GEMM_SPLIT=1: tail rows of a partial round re-tiled 128x256 in a second launch (r01 default; off since the persistent kernel)
     int pp_flags = 0;        // VITX_PP_SCHED=2: the two-burst schedule of the ping-pong kernel (gemm_pp.hip FLAGS 4096) instead of the four-phase one
+    int pp_dbg = 0;          // VITX_PP_DBG: ablation bits of the ping-pong kernel's fused LayerNorm (64 no row pass, 128 no hand-off at all)
+    int ln_fuse = 1;         // VITX_LN_FUSE=0: LayerNorm always as its own kernel (never fused into the proj / fc2 GEMMs)
     int group_m = 0;         // VITX_GROUP_M: raster group height of the ping-pong kernel (0 = its default)
     int gemm_balance = 1;    // VITX_GEMM_BALANCE=0: launch one workgroup per CU even when the last round of tiles is partial
     int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
@@ -69,6 +75,9 @@ struct Tuning {
 const Tuning *tuning_for_device(int device);
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream);
+// true when launch_gemm would run this EPI_BIAS_RESID GEMM on the ping-pong kernel in one launch, so that the LayerNorm of its output
+// rows can be fused into it (GemmArgs::ln_out); the caller then skips the stand-alone layernorm launch
+bool gemm_can_fuse_layernorm(const Tuning &t, const GemmArgs &a);
 int gemm_tile_m();   // M granularity the GEMM needs (buffer row padding)
 int gemm_tile_n();
 

@@ -218,14 +218,24 @@ static int pp_grid(const Tuning &t, const GemmArgs &a) {
     return (int)(g < cap ? g : cap);
 }
 
+static bool is_wide(const Tuning &t, const GemmArgs &a) {
+    const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
+    return a.M % 256 == 0 && a.N_pad % 256 == 0 && t256 >= 128 && (gemm_pp_supports(a) || gemm_ring_supports(a, 445));
+}
+bool gemm_can_fuse_layernorm(const Tuning &t, const GemmArgs &a) {
+    return t.ln_fuse && t.gemm_cfg < 0 && t.gemm_pp && !t.gemm_split && !t.pp_flags && a.M > 0 && is_wide(t, a) && gemm_pp_supports(a) &&
+           a.N == a.ldo && a.N == a.N_pad && a.N % 256 == 0 && a.N <= 1536;
+}
 static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a0, hipStream_t stream) {
-    GemmArgs a = a0; a.group_m = t.group_m;
+    GemmArgs a = a0; a.group_m = t.group_m; a.dbg = t.pp_dbg;
+    if (a.ln_out) return (epi == EPI_BIAS_RESID && gemm_can_fuse_layernorm(t, a)) ? launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, 32768) : hipErrorInvalidValue;
     if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(t, a), stream);
 }
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
+    if (a.ln_out && !gemm_can_fuse_layernorm(t, a)) return hipErrorInvalidValue;      // the caller asks gemm_can_fuse_layernorm first
     int cfg = t.gemm_cfg;
     if (cfg == 1) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     if (cfg > 1) return gemm_ring_supports(a, cfg) ? launch_gemm_ring(t, dtype, epi, a, cfg, stream) : hipErrorInvalidValue;
@@ -1003,7 +1013,8 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
     for (int dt = 0; dt < 2; ++dt) {
         for (int epi = 0; epi <= EPI_PATCH; ++epi) {
             for (int cfg : {945, 445, 245, 122}) if ((e = launch_gemm_ring(t, dt, epi, none, cfg, nullptr, true)) != hipSuccess) return e;
-            for (int fl : {0, 4096}) if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, fl, true)) != hipSuccess) return e;
+            for (int fl : {0, 4096, 8192}) if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, fl, true)) != hipSuccess) return e;
+            if (epi == EPI_BIAS_RESID) { GemmArgs f{}; f.ln_out = (void *)1; f.ln_cnt = (int *)1; f.ln_w = f.ln_b = (const float *)1; f.N = f.ldo = 256; if ((e = launch_gemm_pp(dt, epi, f, t.n_cu, nullptr, 32768, true)) != hipSuccess) return e; }
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16, true>(epi, none, nullptr, true) : launch_gemm_t<__bf16, true>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
@@ -1039,8 +1050,10 @@ const Tuning *tuning_for_device(int device) {
     t->gemm_skinny = getenv("VITX_GEMM_NOSKINNY") == nullptr;
     t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);      // r02: with the persistent ping-pong kernel the two-launch tail split costs 5 % of the step (profiles/r02_forward_sweeps.txt)
     t->gemm_balance = env_int("VITX_GEMM_BALANCE", 1);
-    t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : 0;
+    t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : (env_int("VITX_PP_SCHED", 4) == 8 ? 8192 : 0);
     t->group_m = env_int("VITX_GROUP_M", 0);
+    t->ln_fuse = env_int("VITX_LN_FUSE", 1);
+    t->pp_dbg = env_int("VITX_PP_DBG", 0);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
     const hipError_t e = prepare_device_kernels(*t);
