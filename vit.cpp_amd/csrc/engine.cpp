@@ -471,7 +471,8 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     const int nR = n * c->R;
     {
         ProfScope ps(c, st, PC_LAYERNORM, 0, (double)nR * D * (4 + eb));
-        HIP_TRY(launch_layernorm(dt, sl.X, D, c->norm_w, c->norm_b, sl.Z, D, nR, D, c->hp.eps, st, c->R, (long)N * D));
+        // classifier: one row per image, row stride N*D; ViTSTR: groups of R consecutive token rows (stride D), group stride N*D
+        HIP_TRY(launch_layernorm(dt, sl.X, c->R == 1 ? (long)N * D : (long)D, c->norm_w, c->norm_b, sl.Z, D, nR, D, c->hp.eps, st, c->R, (long)N * D));
     }
     // classifier (vit.cpp:927-928) and class softmax (vit.cpp:931-933)
     float *lg = d_logits ? (float *)d_logits : sl.logits;
