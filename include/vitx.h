@@ -217,7 +217,9 @@ size_t vitx_ctx_weight_bytes(const vitx_ctx *c);
 /* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
 int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* kernel 0 = automatic, 1 = single-pass kernel (N <= 224, 257-288 or 577-608 tokens only), 2 = streaming two-pass kernel (any N),
- * 3 = pipelined two-pass kernel (any N; LDS-DMA double buffering, transposed LDS reads).  All three give bit-identical results. */
+ * 3 = pipelined two-pass kernel (any N; LDS-DMA double buffering, transposed LDS reads), 4 = persistent single-pass kernel (193..224
+ * tokens: one workgroup per CU walks the (image, head) items, the next item's K/V land by LDS-DMA while the current one is computed).
+ * All of them give bit-identical results. */
 int vitx_op_attention_ex(int dtype, int kernel, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* probs = softmax(logits) over num_classes with the reference's fp16 exp rounding (vit.cpp:931). */
 int vitx_op_softmax(const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);

@@ -462,3 +462,26 @@ def test_layernorm_fused_into_residual_gemms_is_bit_identical(pkg, binding, torc
         ctx.close(); model.close()
     assert torch.isfinite(outs["1"]).all()
     assert torch.equal(outs["0"], outs["1"])
+
+
+@pytest.mark.parametrize("n_img,N,H", [(5, 197, 12), (64, 197, 12), (3, 224, 3), (7, 193, 2), (2, 200, 16)])
+def test_persistent_attention_is_bit_identical_to_single_pass(binding, torch_gpu, n_img, N, H):
+    """Kernel 4 (193..224 tokens: persistent workgroups, the next (image, head) item's K/V arriving by LDS-DMA under the current item's
+    softmax, V^T through transposed LDS reads) computes the same products with the same rounding points in the same order as the
+    register-staged single-pass kernel: bit-identical in both operand types, with more items than workgroups (64 x 12 = 768 items
+    on 256 CUs), fewer (3 x 3), and with NaNs planted right behind the tensor (the padded keys 197..223 of the LAST image read
+    there: the buffer descriptor must return zeros)."""
+    torch = torch_gpu
+    D = H * 64
+    g = torch.Generator(device="cuda").manual_seed(n_img * 1000 + N)
+    rows = n_img * N
+    for tdt, dt in ((torch.float16, binding.F16), (torch.bfloat16, binding.BF16)):
+        big = torch.full((rows + 64, 3 * D), float("nan"), device="cuda", dtype=tdt)
+        big[:rows] = (torch.randn((rows, 3 * D), device="cuda", generator=g) * 0.8).to(tdt)
+        outs = []
+        for kernel in (1, 4):
+            out = torch.zeros((rows, D), dtype=tdt, device="cuda")
+            binding.check(binding.lib().vitx_op_attention_ex(dt, kernel, big.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
+            torch.cuda.synchronize(); outs.append(out)
+        assert torch.isfinite(outs[1].float()).all()
+        assert torch.equal(outs[0], outs[1])

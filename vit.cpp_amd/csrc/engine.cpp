@@ -682,12 +682,15 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *a, const void *qs, const voi
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c) { return c ? c->weight_bytes : 0; }
 
 int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
-    if (!qkv || !out || n_img <= 0 || kernel < 0 || (kernel & 15) > 3) return VITX_ERR_ARG;
+    if (!qkv || !out || n_img <= 0 || kernel < 0 || (kernel & 15) > 4) return VITX_ERR_ARG;
     const Tuning *t0 = tuning_for_device(-1);
     if (!t0) { set_error("vitx_op_attention: kernel bring-up failed"); return VITX_ERR_HIP; }
     Tuning t = *t0;
     t.attn_flags = kernel >> 4; kernel &= 15;                // bits 4+: ablation build of the pipelined kernel (tools/attn_bench.py only)
-    if (kernel == 3) t.attn_waves = -1;                      // pipelined two-pass kernel
+    if (kernel == 4) {                                       // persistent single-pass kernel (193..224 tokens)
+        if (N <= 192 || N > 224) { set_error("vitx_op_attention: the persistent kernel takes 193..224 tokens, not %d", N); return VITX_ERR_UNSUPPORTED; }
+        t.attn_waves = -3;
+    } else if (kernel == 3) t.attn_waves = -1;               // pipelined two-pass kernel
     else if (kernel == 2) t.attn_waves = 0;                  // streaming kernel
     else if (kernel == 1) {                                  // single-pass kernel, also where the automatic choice prefers the pipelined one
         if (!attention_single_pass_supports(N)) { set_error("vitx_op_attention: no single-pass instantiation for %d tokens", N); return VITX_ERR_UNSUPPORTED; }

@@ -68,7 +68,8 @@ struct Tuning {
     int gemm_balance = 1;    // VITX_GEMM_BALANCE=0: launch one workgroup per CU even when the last round of tiles is partial
     int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
     int attn_flags = 0;      // ablation build of the pipelined attention kernel (tools/attn_bench.py); 0 = product
-    int attn_waves = 4;      // VITX_ATTN_WAVES
+    int attn_persist = 1;    // VITX_ATTN_PERSIST=0: never the persistent single-pass kernel (193..224 tokens)
+    int attn_waves = 4;      // VITX_ATTN_WAVES (-3: force the persistent kernel where it applies)
 };
 // Looks the device up (hipGetDevice when device < 0), reads the environment once per process, and on first use of a device
 // sets the dynamic-LDS attribute of every kernel instantiation on it.  Thread-safe.  Returns nullptr if HIP fails.

@@ -982,6 +982,194 @@ static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent single-pass attention (vit.cpp:826-866) for 193..224 tokens -- ViT-*/16 at 224^2, the headline configuration.
+// Same arithmetic as attention_kernel (every score tile of a query in registers: same products, rounding points and summation
+// order, bit-identical results); what changes is how K and V reach the LDS.  The r01 ablation (profiles/r01_gemm_ablation.txt G)
+// attributes 40 % of the single-pass kernel to the K/V global loads of its register staging.  Here:
+//   * one persistent workgroup per CU, 8 waves, walks (image, head) items; wave w owns query tile w of the item (7 tiles: the eighth
+//     wave only moves data);
+//   * K (swizzled row image, permutation on the source side) and V (row-major) of item i + 1 land by LDS-DMA in a second 56 KiB
+//     buffer while item i is computed -- no staging registers, no VALU, no LDS transposition; the V^T fragments come out of
+//     ds_read_b64_tr_b16 exactly as in attention_flow_kernel;
+//   * the DMA of the next item is issued AFTER the QK^T products (hipcc waits vmcnt(0) before the first use of the Q registers,
+//     which were loaded one item earlier: nothing else may be in flight then), so it has the softmax and the PV products to land;
+//     one barrier per item.
+// Keys 197..223 read the next image's rows (finite; masked to -inf) or the zeros a buffer load returns out of range.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NKT>
+__global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = NKT * 32, KB = NK * 128, BUF = 2 * KB;       // one item: K image + V image
+    constexpr int PIECES = NK * 8, OPS = (PIECES + 511) / 512;      // 16-byte pieces per image, DMA instructions per thread and image
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef typename Elem<T>::v8 v8;
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const int row_bytes = 3 * D * 2;
+    const bool qwave = wave < NKT;
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)qkv, 0, (int)total_bytes, 0x00020000);
+    // (array bounds are a literal on purpose: hipcc drops the HOST stub of a template kernel -- no diagnostic, an undefined symbol at load
+    // time -- when a lambda captures an array whose bound is a value-dependent constexpr local)
+    static_assert(OPS <= 4, "at most 256 keys");
+    int koff[4], voff[4];
+#pragma unroll
+    for (int it = 0; it < OPS; ++it) {
+        const int p = it * 512 + tid;
+        int rr, sl; swz_inv(p, rr, sl);
+        koff[it] = rr * row_bytes + D * 2 + sl * 16;
+        const int vr = p >> 3, vs = (p & 7) ^ (((vr >> 1) & 1) << 2);           // V image: 16-B slot ^ 4 on rows 2, 3 (mod 4)
+        voff[it] = vr * row_bytes + 2 * D * 2 + vs * 16;
+    }
+    auto item_base = [&](int item) { const int b = item / H, h = item - b * H; return (int)(((size_t)b * N * 3 * D + h * 64) * 2); };     // bytes (< 4 GiB: launcher)
+    auto stage = [&](int item, char *buf) {
+        const int so = __builtin_amdgcn_readfirstlane(item_base(item));
+#pragma unroll
+        for (int it = 0; it < OPS; ++it) {
+            if (it * 512 + wave * 64 < PIECES) {            // wave-uniform: the last instruction covers only part of the image
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + it * 8192 + wave * 1024), 16, koff[it], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + it * 8192 + wave * 1024), 16, voff[it], so, 0, 0);
+            }
+        }
+    };
+    v8 qf[4];
+    auto load_q = [&](int item) {
+        const T *base = qkv + (size_t)item_base(item) / 2;
+        const int qrow = min(wave * 32 + l31, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qrow * 3 * D + ks * 16 + hh * 8);
+    };
+    // fragment addresses (kernel attention_flow_kernel): K tile kt adds kt * 4096, V tile kt adds kt * 32 * 128
+    int krd[4], vrd[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) krd[ks] = swz_byte(l31, ks * 2 + hh);
+    {
+        const int r = 4 * hh + ((lane & 15) >> 2), rb = (r >> 1) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vrd[dt] = KB + r * 128 + ((dt ^ rb) << 6) + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    }
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char *)smem);
+
+    int item = blockIdx.x;
+    if (item >= items) return;
+    int cur_off = 0;
+    stage(item, smem);
+    if (qwave) load_q(item);
+    __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
+    __syncthreads();
+
+    for (; item < items; item += gridDim.x) {
+        const char *cur = smem + cur_off;
+        const int b = item / H, h = item - b * H;
+        const int nitem = item + gridDim.x;
+        f32x16 s[NKT];
+        if (qwave) {
+            // S^T tiles: rows = keys, cols = queries
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s[kt] = Elem<T>::mfma(*(const v8 *)(cur + krd[ks] + kt * 4096), qf[ks], s[kt]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nitem < items) { stage(nitem, smem + (cur_off ^ BUF)); if (qwave) load_q(nitem); }      // lands during the softmax and the PV products
+        __builtin_amdgcn_sched_barrier(0);
+        if (qwave) {
+            const int qrow = wave * 32 + l31;
+            float mxs = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (kt == NKT - 1) {       // only the last key tile can hold padded keys
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (key >= N) s[kt][r] = -INFINITY;
+                    }
+                    mxs = fmaxf(mxs, s[kt][r]);
+                }
+            mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+            const float nmx = -0.125f * mxs;
+            float sum = 0.0f;
+            v8 p[NKT][2];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {      // e = round(exp(round(s/8 - max))) per ggml_soft_max; row sum of the ROUNDED values
+                    const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[kt][r], 0.125f, nmx), __builtin_fmaf(s[kt][r + 1], 0.125f, nmx));
+                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[0], 1.44269504f, 0.0f));
+                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[1], 1.44269504f, 0.0f));
+                    const typename Pair<T>::v2 eh = round_pair<T>(e0, e1);
+                    sum = Pair<T>::sum2(eh, sum);
+                    p[kt][r >> 3][r & 7] = eh[0]; p[kt][r >> 3][(r & 7) + 1] = eh[1];
+                }
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            // O^T = V^T . P^T: rows = head dims (2 tiles of 32), cols = queries; V^T fragments by transposed LDS reads (inline asm: behind the
+            // builtin hipcc waits vmcnt(0) in front of every transposed read while the next item's LDS-DMA is in flight)
+            f32x16 o[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const unsigned cb = lds0 + (unsigned)cur_off + kt * 32 * 128;
+                s4 f[2][2][2];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const unsigned va = cb + vrd[dt];
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt][0][0]) : "v"(va));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f[dt][0][1]) : "v"(va));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[dt][1][0]) : "v"(va));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(f[dt][1][1]) : "v"(va));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]),
+                                                      "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
+                typedef short s8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const s8 both = __builtin_shufflevector(f[dt][half][0], f[dt][half][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[dt] = Elem<T>::mfma(__builtin_bit_cast(v8, both), p[kt][half], o[dt]);
+                    }
+            }
+            if (qrow < N) {
+                T *orow = out + ((size_t)b * N + qrow) * D + h * 64;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        typename Elem<T>::v4 w4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = (T)(o[dt][r4 * 4 + j] * inv);
+                        *(typename Elem<T>::v4 *)(orow + dt * 32 + r4 * 8 + hh * 4) = w4;
+                    }
+            }
+        }
+        // The next item's K / V and Q must have landed; this wave's 8 output stores are YOUNGER than those loads and may stay in flight
+        // (vector-memory operations retire in issue order on gfx9: the counted wait skips exactly the stores, as gemm_pp.hip does).
+        if (qwave) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // every wave is done with this item's buffer; the next one is visible to all
+        cur_off ^= BUF;
+    }
+}
+template <typename T>
+static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img, int N, int D, int H, int n_cu, hipStream_t stream) {
+    constexpr int NKT = 7, lds = 2 * 2 * NKT * 32 * 128;          // two items x (K + V) x 224 rows x 128 B = 112 KiB
+    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
+    const size_t total = (size_t)n_img * N * 3 * D * 2;
+    if (total >= 0xf0000000u) return hipErrorInvalidValue;          // 32-bit buffer offsets
+    const int items = n_img * H;
+    const int grid = items < n_cu ? items : n_cu;
+    hipLaunchKernelGGL((attention_persist_kernel<T, NKT>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total);
+    return hipGetLastError();
+}
+bool attention_persist_supports(int n_img, int N, int D) { return N > 192 && N <= 224 && (size_t)n_img * N * 3 * D * 2 < 0xf0000000u; }
+
 static const int kAttnNkt[] = {1, 2, 3, 4, 5, 6, 7, 9, 19};      // instantiated key-tile counts (tokens = 32 * nkt, rounded up)
 bool attention_single_pass_supports(int N) {
     const int nkt = (N + 31) / 32;
@@ -997,6 +1185,10 @@ hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *o
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
     if (t.attn_waves == 0)
         return dtype == DT_F16 ? launch_attention_stream<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_stream<__bf16>(qkv, out, n_img, N, D, H, stream);
+    // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax); needs
+    // enough items to keep every workgroup busy for a few rounds, otherwise the one-item-per-workgroup kernel starts faster
+    if ((t.attn_waves == -3 || (t.attn_persist && t.attn_waves == 4 && (long)n_img * H >= 2L * t.n_cu)) && attention_persist_supports(n_img, N, D))
+        return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.n_cu, stream) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.n_cu, stream);
     const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_waves == -2);      // -2: vitx_op_attention_ex(kernel 1)
     if (t.attn_waves == -1 || !single)
         return dtype == DT_F16 ? launch_attention_flow<_Float16>(qkv, out, n_img, N, D, H, stream, t.attn_flags) : launch_attention_flow<__bf16>(qkv, out, n_img, N, D, H, stream, t.attn_flags);
@@ -1020,6 +1212,7 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
         }
         if ((e = (dt == DT_F16 ? launch_attention_stream<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_stream<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_flow<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_flow<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
+        if ((e = (dt == DT_F16 ? launch_attention_persist<_Float16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr) : launch_attention_persist<__bf16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr))) != hipSuccess) return e;
         for (int nkt : kAttnNkt) {
             for (int w : {4, 7}) {
                 if (w == 7 && nkt != 7) continue;
@@ -1056,6 +1249,7 @@ const Tuning *tuning_for_device(int device) {
     t->pp_dbg = env_int("VITX_PP_DBG", 0);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
+    t->attn_persist = env_int("VITX_ATTN_PERSIST", 1);
     const hipError_t e = prepare_device_kernels(*t);
     if (cur != device) (void)hipSetDevice(cur);
     if (e != hipSuccess) return nullptr;
