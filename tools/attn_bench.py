@@ -19,9 +19,10 @@ for _ in range(3): B.check(L.vitx_op_attention_ex(DT, kern, qkv.data_ptr(), out.
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(20): L.vitx_op_attention_ex(DT, kern, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, s)
+ITERS = int(os.environ.get('ATTN_ITERS', '20'))
+for _ in range(ITERS): L.vitx_op_attention_ex(DT, kern, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, s)
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 20
+ms = e0.elapsed_time(e1) / ITERS
 print(f"attention kernel {kern} {'bf16' if bf else 'f16'} {n_img}x{H}x{N}: {ms*1e3:.1f} us  {4.0*n_img*H*N*N*64/ms/1e9:.1f} TF/s")
 # check vs torch
 q, k, v = qkv.float().view(n_img, N, 3, H, 64).permute(2, 0, 3, 1, 4)
