@@ -117,3 +117,35 @@ def test_oracle_sequence_head(pkg, oracle, tmp_path):
     z = oracle.layernorm(X[:, :25].reshape(50, om.D), om.tensor("norm.weight"), om.tensor("norm.bias"))
     want = om.linear("head.weight", "head.bias", z, oracle.REF).reshape(2, 25, 96)
     assert np.array_equal(want, logits)
+
+
+def test_vitstr_graph_vs_transformers_f32_and_converter(pkg, oracle, binding, tmp_path):
+    """Independent implementation of the ViTSTR graph: a HuggingFace ViT with ONE input channel (f32, tanh-GELU, eps 1e-6); ViTSTR's
+    forward (extensions/vitstr.cpp/convert-pth-to-ggml.py: forward_features, then the head on x[:, :25]) is the final LayerNorm + the
+    classifier applied to the first 25 tokens.  The converter's --vitstr path writes it as a ViTSTR file; the oracle's no-rounding
+    mode must reproduce the HF logits of all 25 positions, and the product loader must recognise the model kind and labels."""
+    torch = pytest.importorskip("torch")
+    tr = pytest.importorskip("transformers")
+    torch.manual_seed(3)
+    cfg = tr.ViTConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, hidden_act="gelu_pytorch_tanh",
+                       layer_norm_eps=1e-6, image_size=96, patch_size=16, num_channels=1, num_labels=96, hidden_dropout_prob=0.0,
+                       attention_probs_dropout_prob=0.0, qkv_bias=True)
+    m = tr.ViTForImageClassification(cfg).eval()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+    path = str(tmp_path / "vitstr_hf.gguf")
+    hp = pkg.convert.convert_hf_model(m, path, ftype=0, vitstr=True)
+    assert (hp.hidden_size, hp.num_classes, hp.img_size) == (128, 96, 96)
+    pm = binding.Model(path)
+    assert pm.in_channels == 1 and pm.seq_len == 25 and pm.label(1) == "[s]" and pm.label(34) == "A"
+    x = np.clip(np.random.default_rng(9).standard_normal((2, 96, 96)) * 0.5, -1, 1).astype(np.float32)
+    with torch.no_grad():
+        hidden = m.vit(pixel_values=torch.from_numpy(x)[:, None]).last_hidden_state          # [2, 37, 128], final LayerNorm applied
+        hf = m.classifier(hidden[:, :25]).numpy()
+    lg, pr = oracle.OracleModel(path).forward(x, oracle.IDEAL)
+    assert lg.shape == (2, 25, 96)
+    assert np.abs(lg - hf).max() <= 2e-3, np.abs(lg - hf).max()       # the patch kernel is stored in fp16: the only parameter difference
+    with pytest.raises(ValueError):
+        pkg.convert.convert_hf_model(tr.ViTForImageClassification(tr.ViTConfig(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+                                                                              image_size=32, patch_size=16, num_labels=96)).eval(), str(tmp_path / "x.gguf"), vitstr=True)

@@ -47,15 +47,25 @@ def state_dict_to_timm(sd: Dict[str, np.ndarray], num_layers: int) -> Dict[str, 
     return {k: np.ascontiguousarray(np.asarray(v, np.float32)) for k, v in out.items()}
 
 
-def convert_hf_model(model, path: str, ftype: int = 1) -> HParams:
-    """model: transformers.ViTForImageClassification (eval).  Writes `path`; returns the hparams written."""
+def convert_hf_model(model, path: str, ftype: int = 1, vitstr: bool = False) -> HParams:
+    """model: transformers.ViTForImageClassification (eval).  Writes `path`; returns the hparams written.
+    vitstr=True: the model is a ViTSTR scene-text recogniser (/root/reference/extensions/vitstr.cpp/convert-pth-to-ggml.py: a ViT with ONE
+    input channel whose classifier is applied to the first 25 tokens); the file then carries the character set as labels, and the
+    one-channel patch kernel is what makes vit_model_load / vitx_model_load treat it as a ViTSTR model (vitstr.cpp:482)."""
     cfg = model.config
+    if vitstr and getattr(cfg, "num_channels", 3) != 1:
+        raise ValueError("a ViTSTR model takes one (grey) input channel")
     if cfg.hidden_size // cfg.num_attention_heads != 64:
         raise ValueError("the forward path supports head_dim 64 only (every model the reference converts)")
     hp = HParams(cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_labels, cfg.patch_size, cfg.image_size, ftype)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     tensors = state_dict_to_timm(sd, cfg.num_hidden_layers)
     id2label = {int(k): str(v) for k, v in (getattr(cfg, "id2label", None) or {}).items()} or None
+    if vitstr:
+        from .synth import VITSTR_LABELS
+        if cfg.num_labels != len(VITSTR_LABELS):
+            raise ValueError(f"ViTSTR's character set has {len(VITSTR_LABELS)} classes ([GO], [s], 94 printable characters), the model has {cfg.num_labels}")
+        id2label = dict(VITSTR_LABELS)
     write_model(path, hp, tensors, id2label=id2label, ftype=ftype)
     return hp
 
@@ -64,10 +74,11 @@ def main(argv=None) -> int:
     import argparse
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("model"); ap.add_argument("out"); ap.add_argument("--ftype", type=int, default=1, help="0 f32, 1 f16 (default), 2/3/6/7/8 q4_0/q4_1/q5_0/q5_1/q8_0")
+    ap.add_argument("--vitstr", action="store_true", help="one-channel ViTSTR scene-text model: write the character set as labels")
     a = ap.parse_args(argv)
     import transformers
     m = transformers.ViTForImageClassification.from_pretrained(a.model).eval()
-    hp = convert_hf_model(m, a.out, a.ftype)
+    hp = convert_hf_model(m, a.out, a.ftype, vitstr=a.vitstr)
     print(f"wrote {a.out}: hidden {hp.hidden_size}, layers {hp.num_hidden_layers}, heads {hp.num_attention_heads}, classes {hp.num_classes}, patch {hp.patch_size}, img {hp.img_size}, ftype {a.ftype}")
     return 0
 
