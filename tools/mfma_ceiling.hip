@@ -59,6 +59,57 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(Out *out, int iters) {
     if (threadIdx.x == 0) { Out o; o.cycles = c1 - c0; o.realtime = r1 - r0; o.mfmas = (unsigned long long)iters * 32; o.sink = s; out[blockIdx.x] = o; }
 }
 
+// the same loop on v_mfma_f32_16x16x32 (4 accumulator registers per MFMA, 16 cycles each): 64 MFMAs per iteration = the same flops
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int FILL>
+__global__ __launch_bounds__(512, 2) void mfma16_loop(Out *out, int iters) {
+    const int tid = threadIdx.x + blockIdx.x * blockDim.x;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[i][e] = (__bf16)(FILL == 0 ? 0.0f : rnd_unit(tid * 64 + i * 8 + e));
+            b[i][e] = (__bf16)(FILL == 0 ? 0.0f : rnd_unit(tid * 64 + 32 + i * 8 + e) * 0.05f);
+        }
+    f32x4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0, 0, 0, 0};
+    __syncthreads();
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + k) & 3], b[i & 3], acc[i], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+    if (threadIdx.x == 0) { Out o; o.cycles = c1 - c0; o.realtime = r1 - r0; o.mfmas = (unsigned long long)iters * 64; o.sink = s; out[blockIdx.x] = o; }
+}
+template <int FILL>
+static void run16(const char *name, int n_cu, double target_ms) {
+    Out *d; CK(hipMalloc(&d, sizeof(Out) * n_cu));
+    int iters = 2000;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((mfma16_loop<FILL>), dim3(n_cu), dim3(512), 0, 0, d, iters);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (pass == 0) { iters = (int)(iters * target_ms / ms); if (iters < 100) iters = 100; continue; }
+        Out *h = (Out *)malloc(sizeof(Out) * n_cu); CK(hipMemcpy(h, d, sizeof(Out) * n_cu, hipMemcpyDeviceToHost));
+        double cyc = 0, rt = 0; for (int i = 0; i < n_cu; ++i) { cyc += h[i].cycles; rt += h[i].realtime; }
+        const double flops = 2.0 * 16 * 16 * 32 * (double)iters * 64 * 8 * n_cu;
+        printf("%-34s %8.1f TFLOP/s   kernel %7.2f ms   shader clock %6.0f MHz\n", name, flops / (ms * 1e-3) / 1e12, ms, (cyc / n_cu) / ((rt / n_cu) / 100.0));
+        fflush(stdout); free(h);
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+    CK(hipFree(d));
+}
+
 template <typename V, typename E, int FILL, int SLEEP>
 static void run(const char *name, int n_cu, double target_ms) {
     Out *d; CK(hipMalloc(&d, sizeof(Out) * n_cu));
@@ -93,6 +144,8 @@ int main(int argc, char **argv) {
     run<bf16x8, __bf16, 1, 0>("bf16 constant 0.5", n_cu, ms);
     run<bf16x8, __bf16, 2, 0>("bf16 uniform random", n_cu, ms);
     run<half8, _Float16, 2, 0>("f16  uniform random", n_cu, ms);
+    run16<0>("bf16 16x16x32 zero operands", n_cu, ms);
+    run16<2>("bf16 16x16x32 uniform random", n_cu, ms);
     run<bf16x8, __bf16, 2, 1>("bf16 random, s_sleep 1 / 32 MFMA", n_cu, ms);
     run<bf16x8, __bf16, 2, 4>("bf16 random, s_sleep 4 / 32 MFMA", n_cu, ms);
     run<bf16x8, __bf16, 2, 8>("bf16 random, s_sleep 8 / 32 MFMA", n_cu, ms);

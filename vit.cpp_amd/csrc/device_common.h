@@ -18,10 +18,12 @@ template <typename T> struct Elem;
 template <> struct Elem<_Float16> {
     typedef half8 v8; typedef half4 v4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Elem<__bf16> {
     typedef bf16x8 v8; typedef bf16x4 v4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)(T)x; }   // round-trip through the operand type
 

@@ -213,6 +213,112 @@ __device__ __forceinline__ void pp_epilogue_full(f32x16 (&acc)[4][2], __amdgpu_b
     }
 }
 
+// ---- the same two epilogues for the 16x16x32 accumulator layout (FLAGS 65536).  A wave's 128 x 64 block is 8 x 4 tiles of 16 x 16;
+// swapped products: lane (l15 = lane & 15, g4 = lane >> 4) holds row t * 16 + l15 and columns u * 16 + 4 g4 .. + 3 of tile (t, u).
+template <typename T, int EPI, bool FULL>
+__device__ __forceinline__ void pp16_epilogue(const GemmArgs &g, f32x4 (&acc)[8][4], int row0 /* m0 + wave row * 128 + l15 */, int ncol /* first column of the wave */, int g4) {
+    typedef typename Elem<T>::v4 v4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = ncol + u * 16 + g4 * 4;
+        const f32x4 bv = *(const f32x4 *)(g.bias + c);                   // the bias buffer is padded to the N tile
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = row0 + t * 16;
+            const bool ok = FULL || (row < g.M_real && c < g.N);
+            const f32x4 v = acc[t][u] + bv;
+            if constexpr (EPI == EPI_BIAS) {
+                if (ok) *(v4 *)((T *)g.out + (size_t)row * g.ldo + c) = __builtin_convertvector(v, v4);
+            } else if constexpr (EPI == EPI_BIAS_GELU) {
+                const typename Pair<T>::v2 x01 = round_pair<T>(v[0], v[1]), x23 = round_pair<T>(v[2], v[3]);
+                const f32x2 y01 = gelu_tanh2(f32x2{(float)x01[0], (float)x01[1]}), y23 = gelu_tanh2(f32x2{(float)x23[0], (float)x23[1]});
+                const typename Pair<T>::v2 o01 = round_pair<T>(y01[0], y01[1]), o23 = round_pair<T>(y23[0], y23[1]);
+                if (ok) *(v4 *)((T *)g.out + (size_t)row * g.ldo + c) = v4{o01[0], o01[1], o23[0], o23[1]};
+            } else if constexpr (EPI == EPI_BIAS_RESID) {
+                if (ok) { f32x4 *p = (f32x4 *)((float *)g.out + (size_t)row * g.ldo + c); *p = v + *p; }
+            } else if constexpr (EPI == EPI_BIAS_F32) {
+                if (ok) *(f32x4 *)((float *)g.out + (size_t)row * g.ldo + c) = v;
+            } else {   // EPI_PATCH
+                if (ok) {
+                    const int b = row / g.tpi, tk = row - b * g.tpi;
+                    const f32x4 pe = *(const f32x4 *)(g.pos + (size_t)(tk + 1) * g.ldo + c);
+                    *(f32x4 *)((float *)g.out + ((size_t)row + b + 1) * g.ldo + c) = v + pe;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int EPI, int AUX = 0>
+__device__ __forceinline__ void pp16_epilogue_full(f32x4 (&acc)[8][4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int rd_off = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);         // row layout: row (lane>>3) + 8t, 16-byte piece lane&7
+    f32x4 bq[4];                                                                            // bias of columns u * 16 + 4 g4 .. + 3 (staged into the patch by LDS-DMA)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bq[u] = *(const f32x4 *)(patch + u * 64 + g4 * 16);
+    pp_lds_fence();
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        typedef typename Pair<T>::v2 v2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                  // 32-row block i = tiles t = 2i, 2i + 1
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 v = acc[2 * i + tp][u] + bq[u];
+                    v2 p0 = round_pair<T>(v[0], v[1]), p1 = round_pair<T>(v[2], v[3]);
+                    if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
+                        const f32x2 y0 = gelu_tanh2(f32x2{(float)p0[0], (float)p0[1]}), y1 = gelu_tanh2(f32x2{(float)p1[0], (float)p1[1]});
+                        p0 = round_pair<T>(y0[0], y0[1]); p1 = round_pair<T>(y1[0], y1[1]);
+                    }
+                    // columns u * 16 + 4 g4 .. + 3 -> bytes u * 32 + 8 g4 of the 128-byte patch row: 16-byte slot 2u + (g4 >> 1), half g4 & 1
+                    *(u32x2 *)(patch + prow * 128 + (((2 * u + (g4 >> 1)) * 16) ^ x16) + (g4 & 1) * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+                }
+            }
+            pp_lds_fence();
+            u32x4 d[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = *(const u32x4 *)(patch + t * 1024 + rd_off);
+            pp_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pp_store_b128<AUX>(d[t], ro, voff, soff + (i * 4 + t) * soff8);
+        }
+    } else {       // f32 outputs: one 32 x 32 block (4 KiB) per pass
+        u32x4 res[2][4];
+        auto load_res = [&](int c, u32x4 (&dst)[4]) {
+            const int i = c >> 1, j = c & 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+        };
+        if constexpr (EPI == EPI_BIAS_RESID) load_res(0, res[0]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int i = c >> 1, j = c & 1;
+            if constexpr (EPI == EPI_BIAS_RESID) { if (c + 1 < 8) load_res(c + 1, res[(c + 1) & 1]); }
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) {        // columns (2j + uu) * 16 + 4 g4 of the wave = (uu * 16 + 4 g4) of this 32-column block: slot 4 uu + g4
+                    const f32x4 v = acc[2 * i + tp][2 * j + uu] + bq[2 * j + uu];
+                    *(f32x4 *)(patch + prow * 128 + (((4 * uu + g4) * 16) ^ x16)) = v;
+                }
+            }
+            pp_lds_fence();
+            f32x4 d[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = *(const f32x4 *)(patch + t * 1024 + rd_off);
+            pp_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);
+                pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
+            }
+        }
+    }
+}
+
 // LayerNorm of rows m0 .. m0 + nrows - 1 of the f32 matrix the GEMM just completed (g.out, row length g.N = 256 * NV floats), written
 // as operand-type rows to g.ln_out: the arithmetic of layernorm_kernel (kernels.hip) statement for statement -- per lane 4 * NV values
 // (float4 i at element (i * 64 + lane) * 4), sum over i then j, xor-shuffle tree, mean, centred sum of squares, same tree,
@@ -361,24 +467,63 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         rdA[ks] = swz_byte(wr * 64 + l31, ks * 2 + hh);
         rdB[ks] = swz_byte(wc * 32 + l31, ks * 2 + hh);
     }
+    // Products are v_mfma_f32_16x16x32 (FLAGS 65536 = the r02a..r02e 32x32x16 form, kept for A/B): the same LDS images, read volume
+    // and MFMA cycles, but a 16-row fragment is lane & 15 = row, lane >> 4 = which 8 of the 32 k values.  On random operands the
+    // 16x16x32 form costs 11 % less energy per flop (tools/mfma_ceiling.bin: 2032 vs 1814 TFLOP/s at the 1400 W cap) and the forward
+    // is energy-bound: sq8k 1276 -> 1485 TFLOP/s, ViT-B bs256 forward 10.24 -> 9.98 ms, ViT-L/384 51.4 -> 49.5 ms (profiles/r02c).
+    constexpr bool M16 = (FLAGS & 65536) == 0;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    int rdA16[2][2], rdB16[2][2];                    // [16-row tile parity][32-deep k-step]: tiles 2 apart are 32 rows = 4096 bytes apart
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            rdA16[pz][k2] = swz_byte(wr * 64 + pz * 16 + l15, k2 * 4 + g4);
+            rdB16[pz][k2] = swz_byte(wc * 32 + pz * 16 + l15, k2 * 4 + g4);
+        }
     v8 fa[2][4], fb[2][4];
     f32x16 acc[4][2];
+    f32x4 acc16[8][4];
     auto read_a = [&](int buf, int h) {
+        if constexpr (M16) {      // tile t (16 rows) of the half, k-step k2 -> fa[t >> 1][(t & 1) * 2 + k2]
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = *(const v8 *)(smem + off_a(buf, h) + ii * 4096 + rdA[ks]);
+                for (int k2 = 0; k2 < 2; ++k2) fa[t >> 1][(t & 1) * 2 + k2] = *(const v8 *)(smem + off_a(buf, h) + (t >> 1) * 4096 + rdA16[t & 1][k2]);
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = *(const v8 *)(smem + off_a(buf, h) + ii * 4096 + rdA[ks]);
+        }
     };
     auto read_b = [&](int buf, int h) {
+        if constexpr (M16) {      // tile u (16 columns) of the half, k-step k2 -> fb[h][u * 2 + k2]
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fb[h][ks] = *(const v8 *)(smem + off_b(buf, h) + rdB[ks]);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) fb[h][u * 2 + k2] = *(const v8 *)(smem + off_b(buf, h) + rdB16[u][k2]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb[h][ks] = *(const v8 *)(smem + off_b(buf, h) + rdB[ks]);
+        }
     };
     // MFMAs [first, last) of a quadrant's 8 (k-step major, so consecutive MFMAs alternate between its two accumulators)
     auto mma = [&](int ha, int hb, int first, int last) {
+        if constexpr (M16) {      // 16 MFMAs of 16 cycles = the same 256 cycles; k-step major, 8 independent accumulators in between
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int ks = n >> 1, ii = n & 1;
-            if (n >= first && n < last) acc[2 * ha + ii][hb] = Elem<T>::mfma(fb[hb][ks], fa[ii][ks], acc[2 * ha + ii][hb]);
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc16[ha * 4 + t][hb * 2 + u] = Elem<T>::mfma16(fb[hb][u * 2 + k2], fa[t >> 1][(t & 1) * 2 + k2], acc16[ha * 4 + t][hb * 2 + u]);
+        } else {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const int ks = n >> 1, ii = n & 1;
+                if (n >= first && n < last) acc[2 * ha + ii][hb] = Elem<T>::mfma(fb[hb][ks], fa[ii][ks], acc[2 * ha + ii][hb]);
+            }
         }
     };
 
@@ -447,10 +592,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     int bias_so = 0;                                 // byte offset of the consumer tile's bias columns
     __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, (int)0xffffffffu, 0x00020000);
     auto zero_quadrant = [&](int ha, int hb) {
+        if constexpr (M16) {
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[2 * ha + ii][hb][r] = 0.0f;
+                for (int u = 0; u < 2; ++u) acc16[ha * 4 + t][hb * 2 + u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[2 * ha + ii][hb][r] = 0.0f;
+        }
     };
     auto stage_bias = [&]() { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, LPTR(smem + LDS + wave * 4096), 4, lane * 4, bias_so, 0, 0); };
     auto ktile = [&](auto bc, bool first) {
@@ -525,7 +677,21 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         // Aligning the rows here (and restoring the offset after the epilogue) lets both epilogues run at the same time: forward
         // 10.82 -> 10.75 ms, fc1 +4 % (r02c; FLAGS 8192 = the unaligned r02a behaviour, kept for A/B).
         if constexpr ((FLAGS & 8192) == 0) { if (!(FLAGS & 2) && wr == 0) pp_barrier(); }
-        if constexpr ((FLAGS & 2048) != 0) {
+        if constexpr (M16) {
+            if constexpr ((FLAGS & 2048) != 0) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc16[t][0]), "v"(acc16[t][1]), "v"(acc16[t][2]), "v"(acc16[t][3]));
+            } else if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
+                constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
+                const int voff = ((wr * 128 + (lane >> 3)) * g.ldo + wc * 64) * esz + (lane & 7) * 16;
+                pp16_epilogue_full<T, EPI, (FLAGS & 32768) ? 16 : 0>(acc16, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
+                relaxed = true;
+            } else {
+                const int row0 = m0 + wr * 128 + l15, ncol = n0 + wc * 64;
+                if (full) pp16_epilogue<T, EPI, true>(g, acc16, row0, ncol, g4);
+                else pp16_epilogue<T, EPI, false>(g, acc16, row0, ncol, g4);
+            }
+        } else if constexpr ((FLAGS & 2048) != 0) {
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));
         } else if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
             constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
@@ -605,6 +771,16 @@ static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t 
         case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 8192>(a, n_cu, stream, prepare);
         case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 8192>(a, n_cu, stream, prepare);
         case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 8192>(a, n_cu, stream, prepare);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (flags == 65536) {      // v_mfma_32x32x16 products (the r02a..r02e kernel): every epilogue
+        switch (epi) {
+        case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 65536>(a, n_cu, stream, prepare);
+        case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 65536>(a, n_cu, stream, prepare);
+        case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 65536>(a, n_cu, stream, prepare);
+        case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 65536>(a, n_cu, stream, prepare);
+        case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 65536>(a, n_cu, stream, prepare);
         default: return hipErrorInvalidValue;
         }
     }

@@ -3,8 +3,9 @@
 //   C[M][N] = A[M][K] . W[N][K]^T   (+ fused epilogue), A/W fp16 or bf16, f32 accumulate.
 //
 // Design (MI355X-first, see DESIGN.md "GEMM"):
-//   * waves are laid out 2(M) x 4(N); each wave owns (WMT*32) x 64 of C as WMT x 2 MFMA 32x32x16
-//     accumulators: 8 waves, tile 256x256 (WMT=4, cfg 445/945) or 128x256 (WMT=2, cfg 245: short M and
+//   * waves are laid out 2(M) x 4(N); each wave owns (WMT*32) x 64 of C as 2 WMT x 4 accumulators of
+//     v_mfma_f32_16x16x32 (11 % less energy per flop than 32x32x16 on this power-capped part, see gemm_pp.hip):
+//     8 waves, tile 256x256 (WMT=4, cfg 445/945) or 128x256 (WMT=2, cfg 245: short M and
 //     the remainder rows of a launch), one workgroup per CU, ring of 5 slots (160 / 120 KiB LDS).
 //   * cfg 945 (default for the wide tile) is PERSISTENT: one workgroup per CU walks its tiles and keeps
 //     the ring running across tile boundaries (gemm_stream_kernel below).
@@ -12,10 +13,12 @@
 //     Slots are filled by LDS-DMA (global_load_lds dwordx4) issued NS-1 slots ahead and retired with
 //     COUNTED s_waitcnt vmcnt(N) + one raw s_barrier per slot, so loads stay in flight across
 //     barriers (the compiler's __syncthreads() would drain them).
-//   * fragment registers are double buffered across 16-deep k-steps: the ds_read_b128 of step j+1
-//     (possibly in the next, already-landed slot) are issued under the MFMAs of step j -- MFMA FIRST, then
-//     one read per MFMA (sched_group_barrier), so the lgkmcnt(0) in front of a k-step waits on reads that
-//     are 2+ MFMAs old instead of on the reads just issued (+5-7 %).
+//   * a slot is ONE 32-deep k-step, consumed in two half-steps (upper / lower half of the wave's rows x all of its
+//     columns).  Fragment registers are double buffered: the A fragments of the other half (and, under the second
+//     half-step, the W and first A fragments of the next, already-landed slot) are read under the MFMAs of the current
+//     half-step -- MFMA FIRST, then one read per MFMA (sched_group_barrier), so the lgkmcnt(0) in front of a half-step
+//     waits on reads that are 2+ MFMAs old instead of on the reads just issued (+5-7 %).  The W buffer alternates with
+//     the slot parity: the slot loop is unrolled by two (K % 64 == 0).
 //   * 64-byte LDS rows, 4 rows per 256-B bank line, 16-B slots XOR-ed with (line & 15): every
 //     ds_read_b128 lane group hits 16 distinct slots (conflict-free); the LDS image itself is
 //     lane-linear (DMA requirement), the permutation is applied to the per-lane global source address.
@@ -25,9 +28,11 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_common.h"
 #include "kernels.h"
+#include "epilogue16.h"
 
 #ifndef RING_SCHED
 #define RING_SCHED 1
@@ -51,88 +56,17 @@ __device__ __forceinline__ void swz64_inv(int p, int &row, int &s) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// Bias of the wave's WNT column tiles (this lane's column of each), 0 beyond N.
-template <int WNT>
-__device__ __forceinline__ void load_bias(const GemmArgs &g, int col0, float (&bv)[WNT]) {
+// "1 MFMA, then one LDS read per MFMA, then the rest": R reads under MF MFMAs
+template <int R, int MF>
+__device__ __forceinline__ void sched_half_step() {
+    constexpr int n = R < MF - 1 ? R : MF - 1;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #pragma unroll
-    for (int j = 0; j < WNT; ++j) { const int c = col0 + j * 32; bv[j] = c < g.N ? g.bias[c] : 0.0f; }
+    for (int q = 0; q < n; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+    if constexpr (R > n) __builtin_amdgcn_sched_group_barrier(0x100, R - n, 0);
+    if constexpr (MF - 1 - n > 0) __builtin_amdgcn_sched_group_barrier(0x008, MF - 1 - n, 0);
 }
-
-// Fused epilogue of one wave's (WMT*32) x 64 accumulator block.  FULL tiles skip every bounds check.
-// C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-template <typename T, int EPI, int WMT, int WNT, bool FULL>
-__device__ __forceinline__ void epilogue(const GemmArgs &g, f32x16 (&acc)[WMT][WNT], int row0, int col0, const float (&bv)[WNT]) {
-    bool col_ok[WNT];
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) col_ok[j] = FULL || (col0 + j * 32) < g.N;
-    if constexpr (EPI == EPI_BIAS_RESID) {
-        // read-modify-write of the f32 residual stream in units of 16 loads (one 32x32 accumulator tile): the loads of unit
-        // u+1 are issued BEFORE the adds/stores of unit u, so only the first unit's load latency is exposed.  (Two 32-load
-        // batches in flight need 32 more registers than the K loop leaves: 60 spills, fc2 340 -> 474 us.)
-        float res[2][16];
-        auto load_unit = [&](int u, float (&dst)[16]) {          // unit u = (32-row block u/WNT, column tile u%WNT): 16 rows x this lane's column
-            const int i = u / WNT, j = u % WNT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                const bool ok = FULL || (col_ok[j] && row < g.M_real);
-                dst[r] = ok ? ((const float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] : 0.0f;
-            }
-        };
-        load_unit(0, res[0]);
-#pragma unroll
-        for (int u = 0; u < WNT * WMT; ++u) {
-            if (u + 1 < WNT * WMT) load_unit(u + 1, res[(u + 1) & 1]);
-            const int i = u / WNT, j = u % WNT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (!FULL && !(col_ok[j] && row < g.M_real)) continue;
-                ((float *)g.out)[(size_t)row * g.ldo + col0 + j * 32] = (acc[i][j][r] + bv[j]) + res[u & 1][r];
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < WMT; ++i) {
-        if constexpr (EPI == EPI_BIAS_RESID) {
-        } else {
-#pragma unroll
-            for (int j = 0; j < WNT; ++j) {
-                const int col = col0 + j * 32;
-                if constexpr (EPI == EPI_BIAS_GELU) {
-                    // two rows at a time: bias, round to the operand type (ggml's fp16 LUT input), packed tanh-GELU, round
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);          // r even: rows `row` and `row + 1`
-                        const typename Pair<T>::v2 xin = round_pair<T>(acc[i][j][r] + bv[j], acc[i][j][r + 1] + bv[j]);
-                        const f32x2 y = gelu_tanh2(f32x2{(float)xin[0], (float)xin[1]});
-                        const typename Pair<T>::v2 yo = round_pair<T>(y[0], y[1]);
-                        if (FULL || (col_ok[j] && row < g.M_real)) ((T *)g.out)[(size_t)row * g.ldo + col] = yo[0];
-                        if (FULL || (col_ok[j] && row + 1 < g.M_real)) ((T *)g.out)[(size_t)(row + 1) * g.ldo + col] = yo[1];
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (!FULL && !(col_ok[j] && row < g.M_real)) continue;
-                    const float v = acc[i][j][r] + bv[j];
-                    if constexpr (EPI == EPI_BIAS) {
-                        ((T *)g.out)[(size_t)row * g.ldo + col] = (T)v;
-                    } else if constexpr (EPI == EPI_BIAS_GELU) {
-                        ((T *)g.out)[(size_t)row * g.ldo + col] = (T)gelu_tanh(rnd<T>(v));
-                    } else if constexpr (EPI == EPI_BIAS_F32) {
-                        ((float *)g.out)[(size_t)row * g.ldo + col] = v;
-                    } else {   // EPI_PATCH
-                        const int b = row / g.tpi, t = row - b * g.tpi;
-                        ((float *)g.out)[((size_t)row + b + 1) * g.ldo + col] = v + g.pos[(size_t)(t + 1) * g.ldo + col];
-                    }
-                }
-            }
-        }
-    }
-}
+typedef std::integral_constant<int, 0> RI0; typedef std::integral_constant<int, 1> RI1;
 
 template <typename T, int EPI, int WMT, int WNT, int NWM, int NWN, int NS, int KS, bool DBG>
 __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ? 1 : (NWM * NWN * 64) / 256) void gemm_ring_kernel(GemmArgs g) {
@@ -148,7 +82,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
     typedef typename Elem<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    static_assert(KS == 2 && NS > 2, "ring kernel: 64-byte rows (one 32-deep k-step per slot), ring of >= 3 slots");
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
     const int dbg = DBG ? g.dbg : 0;
@@ -180,23 +115,18 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
         for (int i = 0; i < W_PIECES; ++i) __builtin_amdgcn_global_load_lds(GPTR(W + woff[i] + k0), LPTR(base + A_BYTES + i * PIECE_STRIDE), 16, 0, 0);
     };
 
-    // ---- fragment read offsets within a slot: row = wave base + tile*32 + l31, 16-B slot = ks*2 + hh
-    int a_rd[WMT][KS], w_rd[WNT][KS];
+    // ---- fragment read offsets within a slot: row = wave base + tile*16 + l15, 16-B slot = g4 (which 8 of the slot's 32 k values)
+    int a_rd[2 * WMT], w_rd[2 * WNT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int t = 0; t < 2 * WMT; ++t) a_rd[t] = swz64_byte(wm * (WMT * 32) + t * 16 + l15, g4);
 #pragma unroll
-        for (int i = 0; i < WMT; ++i) { const int r = wm * (WMT * 32) + i * 32 + l31; a_rd[i][ks] = KS == 2 ? swz64_byte(r, ks * 2 + hh) : swz_byte(r, ks * 2 + hh); }
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) { const int r = wn * (WNT * 32) + j * 32 + l31; w_rd[j][ks] = A_BYTES + (KS == 2 ? swz64_byte(r, ks * 2 + hh) : swz_byte(r, ks * 2 + hh)); }
-    }
+    for (int u = 0; u < 2 * WNT; ++u) w_rd[u] = A_BYTES + swz64_byte(wn * (WNT * 32) + u * 16 + l15, g4);
 
-    f32x16 acc[WMT][WNT];
+    f32x4 acc[2 * WMT][2 * WNT];
 #pragma unroll
-    for (int i = 0; i < WMT; ++i)
+    for (int t = 0; t < 2 * WMT; ++t)
 #pragma unroll
-        for (int j = 0; j < WNT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int u = 0; u < 2 * WNT; ++u) acc[t][u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int nslots = g.K / RBK;
     // ---- prologue: NS-1 slots in flight, slots 0 and 1 landed
@@ -209,69 +139,62 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
     }
     wg_barrier();
 
-    v8 fa[2][WMT], fw[2][WNT];
-    auto load_frags = [&](int buf, int pos, int ks) {
+    // fa[h]: A fragments of row half h (tiles h * WMT ..); fw[p]: all W fragments of a slot of parity p
+    v8 fa[2][WMT], fw[2][2 * WNT];
+    auto load_a = [&](int h, int pos) {
         const char *sb = smem + pos * SLOT_BYTES;
 #pragma unroll
-        for (int j = 0; j < WNT; ++j) fw[buf][j] = *(const v8 *)(sb + w_rd[j][ks]);
-#pragma unroll
-        for (int i = 0; i < WMT; ++i) fa[buf][i] = *(const v8 *)(sb + a_rd[i][ks]);
+        for (int t = 0; t < WMT; ++t) fa[h][t] = *(const v8 *)(sb + a_rd[h * WMT + t]);
     };
-    auto mma = [&](int buf) {
+    auto load_w = [&](int p, int pos) {
+        const char *sb = smem + pos * SLOT_BYTES;
 #pragma unroll
-        for (int i = 0; i < WMT; ++i)
-#pragma unroll
-            for (int j = 0; j < WNT; ++j) acc[i][j] = Elem<T>::mfma(fa[buf][i], fw[buf][j], acc[i][j]);
+        for (int u = 0; u < 2 * WNT; ++u) fw[p][u] = *(const v8 *)(sb + w_rd[u]);
     };
-    if (NS > 2) load_frags(0, 0, 0);
+    auto mma = [&](int h, int p) {
+#pragma unroll
+        for (int t = 0; t < WMT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2 * WNT; ++u) acc[h * WMT + t][u] = Elem<T>::mfma16(fw[p][u], fa[h][t], acc[h * WMT + t][u]);
+    };
+    load_w(0, 0); load_a(0, 0);
 
     long long t_cyc = 0, t_real = 0;
     if (DBG && (dbg & 32)) { t_cyc = __builtin_readcyclecounter(); t_real = wall_clock64(); }
-    if (DBG && (dbg & 2)) load_frags(1, 0, 1);
+    if (DBG && (dbg & 2)) { load_a(1, 0); load_w(1, 0); }
     int pos = 0;                                    // ring position of slot i
-    for (int i = 0; i < nslots; ++i) {
+    auto slot = [&](auto pc, int i) {
+        constexpr int P = decltype(pc)::value;      // slot parity = which W fragment buffer it uses
         const int pos_next = (pos + 1 == NS) ? 0 : pos + 1;
         const int pos_fill = (pos == 0) ? NS - 1 : pos - 1;     // = (i + NS - 1) % NS, freed by the barrier that ended iteration i-1
         if (i + NS - 1 < nslots && !(dbg & 1)) issue(i + NS - 1, pos_fill);
-        if (NS == 2 && !(dbg & 2)) load_frags(0, pos, 0);                      // double buffer: the slot only became visible at the barrier
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (!(dbg & 2)) {
-                if (ks + 1 < KS) load_frags((ks + 1) & 1, pos, ks + 1);
-#if RING_SCHED
-                else if (NS > 2) load_frags((ks + 1) & 1, pos_next, 0);                     // unconditional: keeps the k-step one scheduling region (stale data past the end is never used)
-#else
-                else if (NS > 2 && i + 1 < nslots) load_frags((ks + 1) & 1, pos_next, 0);   // slot i+1 landed one iteration ago
-#endif
-            }
-            if (!(dbg & 4)) mma(ks & 1);
-#if RING_SCHED
-            // MFMA first (its operands were read during the previous k-step), then one LDS read per MFMA
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-            for (int q = 0; q < (WMT + WNT) / RING_SCHED; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, RING_SCHED, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
-            if constexpr (WMT * WNT - 1 - (WMT + WNT) / RING_SCHED > 0) __builtin_amdgcn_sched_group_barrier(0x008, WMT * WNT - 1 - (WMT + WNT) / RING_SCHED, 0);
-#endif
-        }
+        // upper half of the rows; the lower half's A fragments are read underneath
+        if (!(dbg & 2)) load_a(1, pos);
+        if (!(dbg & 4)) mma(0, P);
+        sched_half_step<WMT, WMT * 2 * WNT>();
+        // lower half; slot i+1 landed one iteration ago (stale data past the end is never used): its W and first A fragments
+        if (!(dbg & 2)) { load_w(P ^ 1, pos_next); load_a(0, pos_next); }
+        if (!(dbg & 4)) mma(1, P);
+        sched_half_step<WMT + 2 * WNT, WMT * 2 * WNT>();
         // slot i+2 must have landed before the next iteration's prefetch of it; later slots stay in flight
         if (!(dbg & 16)) {
             const int keep = min(i + NS - 1, nslots - 1) - (i + 2);            // slots allowed in flight (may be < 0)
-            if (NS == 2) wait_vmcnt<0>();
-            else if (NS > 3 && keep >= NS - 3) wait_vmcnt<(NS > 3 ? NS - 3 : 0) * G>();
+            if (NS > 3 && keep >= NS - 3) wait_vmcnt<(NS > 3 ? NS - 3 : 0) * G>();
             else if (NS > 4 && keep == 1) wait_vmcnt<G>();
             else wait_vmcnt<0>();
             wg_barrier();
         }
         pos = pos_next;
-    }
+    };
+    for (int i = 0; i < nslots; i += 2) { slot(RI0{}, i); slot(RI1{}, i + 1); }     // K % 64 == 0 (gemm_ring_supports)
 
     if (DBG && (dbg & 8)) {          // experiments: keep the accumulators and fragments alive, store nothing
         if (dbg & 4) { asm volatile("" ::"v"(fa[0][0]), "v"(fa[1][0]), "v"(fw[0][0]), "v"(fw[1][0])); }
         float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < WMT; ++i)
+        for (int t = 0; t < 2 * WMT; ++t)
 #pragma unroll
-            for (int j = 0; j < WNT; ++j) s += acc[i][j][0] + acc[i][j][15];
+            for (int u = 0; u < 2 * WNT; ++u) s += acc[t][u][0] + acc[t][u][3];
         if (s == 1234.5678f) ((float *)g.out)[0] = s;
         if ((dbg & 32) && tid == 0) {   // per-block timeline: K-loop start/end on the 100 MHz wall clock, shader cycles
             long long *d = (long long *)g.pos + (size_t)bid * 4;
@@ -280,10 +203,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
         return;
     }
     const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
-    float bv[WNT];
-    load_bias<WNT>(g, n0 + wn * (WNT * 32) + l31, bv);
-    if (full) epilogue<T, EPI, WMT, WNT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
-    else epilogue<T, EPI, WMT, WNT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
+    if (full) epilogue16<T, EPI, 2 * WMT, 2 * WNT, true>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
+    else epilogue16<T, EPI, 2 * WMT, 2 * WNT, false>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
 }
 
 // ---- persistent variant: one workgroup per CU walks tiles v = bid, bid + grid, ... and keeps ONE ring running
@@ -305,7 +226,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN * 64) / 256) void gemm_s
     typedef typename Elem<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
 
@@ -352,28 +273,28 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN * 64) / 256) void gemm_s
         }
     };
 
-    int a_rd[WMT][KS], w_rd[WNT][KS];
+    int a_rd[2 * WMT], w_rd[2 * WNT];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int t = 0; t < 2 * WMT; ++t) a_rd[t] = swz64_byte(wm * (WMT * 32) + t * 16 + l15, g4);
 #pragma unroll
-        for (int i = 0; i < WMT; ++i) a_rd[i][ks] = swz64_byte(wm * (WMT * 32) + i * 32 + l31, ks * 2 + hh);
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) w_rd[j][ks] = A_BYTES + swz64_byte(wn * (WNT * 32) + j * 32 + l31, ks * 2 + hh);
-    }
-    v8 fa[2][WMT], fw[2][WNT];
-    auto load_frags = [&](int buf, int pos, int ks) {
+    for (int u = 0; u < 2 * WNT; ++u) w_rd[u] = A_BYTES + swz64_byte(wn * (WNT * 32) + u * 16 + l15, g4);
+    v8 fa[2][WMT], fw[2][2 * WNT];                   // as in gemm_ring_kernel: A per row half, W per slot parity
+    auto load_a = [&](int h, int pos) {
         const char *sb = smem + pos * SLOT_BYTES;
 #pragma unroll
-        for (int j = 0; j < WNT; ++j) fw[buf][j] = *(const v8 *)(sb + w_rd[j][ks]);
-#pragma unroll
-        for (int i = 0; i < WMT; ++i) fa[buf][i] = *(const v8 *)(sb + a_rd[i][ks]);
+        for (int t = 0; t < WMT; ++t) fa[h][t] = *(const v8 *)(sb + a_rd[h * WMT + t]);
     };
-    f32x16 acc[WMT][WNT];
-    auto mma = [&](int buf) {
+    auto load_w = [&](int p, int pos) {
+        const char *sb = smem + pos * SLOT_BYTES;
 #pragma unroll
-        for (int i = 0; i < WMT; ++i)
+        for (int u = 0; u < 2 * WNT; ++u) fw[p][u] = *(const v8 *)(sb + w_rd[u]);
+    };
+    f32x4 acc[2 * WMT][2 * WNT];
+    auto mma = [&](int h, int p) {
 #pragma unroll
-            for (int j = 0; j < WNT; ++j) acc[i][j] = Elem<T>::mfma(fa[buf][i], fw[buf][j], acc[i][j]);
+        for (int t = 0; t < WMT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2 * WNT; ++u) acc[h * WMT + t][u] = Elem<T>::mfma16(fw[p][u], fa[h][t], acc[h * WMT + t][u]);
     };
     if (S == 0) return;
 
@@ -382,51 +303,44 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN * 64) / 256) void gemm_s
     for (int s = 0; s < NS - 1; ++s) if (issued < S) issue_next();
     if (S >= NS - 1) wait_vmcnt<(NS - 3) * G>(); else wait_vmcnt<0>();
     wg_barrier();
-    load_frags(0, 0, 0);
+    load_w(0, 0); load_a(0, 0);
 
     int pos = 0, gi = 0;                            // ring position / global index of the slot being consumed
-    for (int round = 0; round < my_tiles; ++round) {
-        // the tile's bias is fetched now and is known complete at the drain wait below (a compiler-visible s_waitcnt:
-        // no load may stay pending into the next round, or hipcc guards the loop's register reuse with vmcnt(0))
-        int m0, n0; tile_origin(round, m0, n0);
-        float bv[WNT];
-        load_bias<WNT>(g, n0 + wn * (WNT * 32) + l31, bv);
-#pragma unroll
-        for (int i = 0; i < WMT; ++i)
-#pragma unroll
-            for (int j = 0; j < WNT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-        for (int i = 0; i < nslots; ++i, ++gi) {
-            const int pos_next = (pos + 1 == NS) ? 0 : pos + 1;
-            if (issued < S) issue_next();           // slot gi+NS-1 into the position freed by the barrier that ended slot gi-1
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 1 < KS) load_frags((ks + 1) & 1, pos, ks + 1);
-                else load_frags((ks + 1) & 1, pos_next, 0);      // slot gi+1 (possibly the next tile's first) landed one iteration ago
-                mma(ks & 1);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-                for (int q = 0; q < WMT + WNT; ++q) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
-                __builtin_amdgcn_sched_group_barrier(0x008, WMT * WNT - 1 - (WMT + WNT), 0);
-            }
-            // slot gi+2 must have landed before the next iteration prefetches its fragments
-            const bool tile_end = (i == nslots - 1);
-            if (tile_end) __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) drain: nothing in flight during the epilogue's stores
-            else if (round > 0 && i < NS - 3) { /* slots gi+2 <= first NS-1 of this tile: drained before the previous epilogue */ }
-            else {
-                const int keep = min(gi + NS - 1, S - 1) - (gi + 2);         // slots allowed to stay in flight
-                if (keep >= NS - 3) wait_vmcnt<(NS - 3) * G>();
-                else if (NS > 4 && keep == 1) wait_vmcnt<G>();
-                else wait_vmcnt<0>();
-            }
-            wg_barrier();
-            pos = pos_next;
+    int round = 0;
+    auto slot = [&](auto pc, int i) {
+        constexpr int P = decltype(pc)::value;
+        const int pos_next = (pos + 1 == NS) ? 0 : pos + 1;
+        if (issued < S) issue_next();               // slot gi+NS-1 into the position freed by the barrier that ended slot gi-1
+        load_a(1, pos);
+        mma(0, P);
+        sched_half_step<WMT, WMT * 2 * WNT>();
+        load_w(P ^ 1, pos_next); load_a(0, pos_next);            // slot gi+1 (possibly the next tile's first) landed one iteration ago
+        mma(1, P);
+        sched_half_step<WMT + 2 * WNT, WMT * 2 * WNT>();
+        // slot gi+2 must have landed before the next iteration prefetches its fragments
+        const bool tile_end = (i == nslots - 1);
+        if (tile_end) __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0) drain: nothing in flight during the epilogue's stores
+        else if (round > 0 && i < NS - 3) { /* slots gi+2 <= first NS-1 of this tile: drained before the previous epilogue */ }
+        else {
+            const int keep = min(gi + NS - 1, S - 1) - (gi + 2);         // slots allowed to stay in flight
+            if (keep >= NS - 3) wait_vmcnt<(NS - 3) * G>();
+            else if (NS > 4 && keep == 1) wait_vmcnt<G>();
+            else wait_vmcnt<0>();
         }
+        wg_barrier();
+        pos = pos_next; ++gi;
+    };
+    for (; round < my_tiles; ++round) {
+        int m0, n0; tile_origin(round, m0, n0);
+#pragma unroll
+        for (int t = 0; t < 2 * WMT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2 * WNT; ++u) acc[t][u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = 0; i < nslots; i += 2) { slot(RI0{}, i); slot(RI1{}, i + 1); }     // nslots is even: the parity restarts with every tile
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) again, unconditionally and visible to hipcc (free: the last slot's wait drained everything)
         const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
-        if (full) epilogue<T, EPI, WMT, WNT, true>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
-        else epilogue<T, EPI, WMT, WNT, false>(g, acc, m0 + wm * (WMT * 32) + 4 * hh, n0 + wn * (WNT * 32) + l31, bv);
+        if (full) epilogue16<T, EPI, 2 * WMT, 2 * WNT, true>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
+        else epilogue16<T, EPI, 2 * WMT, 2 * WNT, false>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
     }
 }
 
@@ -495,7 +409,7 @@ bool gemm_ring_supports(const GemmArgs &a, int cfg) {
     RingCfg c;
     if (!parse_cfg(cfg, c)) return false;
     if (cfg == 945 && a.K < 16 * c.ks * c.ns) return false;
-    return a.M % (c.nwm * c.wmt * 32) == 0 && a.N_pad % (c.nwn * c.wnt * 32) == 0 && a.K % (16 * c.ks) == 0 && a.K >= 32 * c.ks;
+    return a.M % (c.nwm * c.wmt * 32) == 0 && a.N_pad % (c.nwn * c.wnt * 32) == 0 && a.K % (32 * c.ks) == 0 && a.K >= 32 * c.ks;     // slot pairs: K % 64 == 0
 }
 
 hipError_t launch_gemm_ring(const Tuning &t, int dtype, int epi, const GemmArgs &a0, int cfg, hipStream_t stream, bool prepare) {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "epilogue16.h"
 #include "device_common.h"
 
 namespace vitx {
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hh = lane >> 5;
+    const int l15 = lane & 15, g4 = lane >> 4;
 
     // XCD-aware tile order: blocks b, b+8, b+16, ... (same XCD, co-resident) get consecutive tile ids,
     // which share the same A row panel (n fastest).  Bijective for any grid size.
@@ -95,22 +96,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     };
 
     const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][2];
+    f32x4 acc[4][4];                                  // the wave's 64 x 64 block as 4 x 4 tiles of v_mfma_f32_16x16x32 (epilogue16.h)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // fragment read addresses: row = w*64 + i*32 + l31, slot = ks*2 + hh
-    int a_rd[2][4], w_rd[2][4];
+    // fragment read addresses: row = w*64 + t*16 + l15, 16-byte slot = k2*4 + g4 (k-step k2 = 32 of the K-tile's 64)
+    int a_rd[4][2], w_rd[4][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            a_rd[i][ks] = swz_byte(wm * 64 + i * 32 + l31, ks * 2 + hh);
-            w_rd[i][ks] = G_TILE_BYTES + swz_byte(wn * 64 + i * 32 + l31, ks * 2 + hh);
+        for (int k2 = 0; k2 < 2; ++k2) {
+            a_rd[t][k2] = swz_byte(wm * 64 + t * 16 + l15, k2 * 4 + g4);
+            w_rd[t][k2] = G_TILE_BYTES + swz_byte(wn * 64 + t * 16 + l15, k2 * 4 + g4);
         }
 
     const int nk = g.K / GBK;
@@ -123,53 +122,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         if (kt + 1 < nk) { stage(cur ^ 1, (kt + 1) * GBK); if constexpr (Q4) load_q4(kt + 1); }
         const char *sb = smem + cur * G_STAGE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            typename Elem<T>::v8 af[2], wf[2];
+        for (int k2 = 0; k2 < 2; ++k2) {
+            typename Elem<T>::v8 af[4], wf[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *(const typename Elem<T>::v8 *)(sb + a_rd[i][ks]);
-                wf[i] = *(const typename Elem<T>::v8 *)(sb + w_rd[i][ks]);
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const typename Elem<T>::v8 *)(sb + a_rd[t][k2]);
+                wf[t] = *(const typename Elem<T>::v8 *)(sb + w_rd[t][k2]);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = Elem<T>::mfma(af[i], wf[j], acc[i][j]);
+                for (int u = 0; u < 4; ++u) acc[t][u] = Elem<T>::mfma16(wf[u], af[t], acc[t][u]);
         }
         if constexpr (Q4) { if (kt + 1 < nk) write_q4(cur ^ 1); }     // the other buffer: every wave finished reading it before the previous barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // epilogue.  C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (row >= g.M_real) continue;
-                float v = acc[i][j][r] + bv;
-                if (EPI == EPI_BIAS) {
-                    ((T *)g.out)[(size_t)row * g.ldo + col] = (T)v;
-                } else if (EPI == EPI_BIAS_GELU) {
-                    ((T *)g.out)[(size_t)row * g.ldo + col] = (T)gelu_tanh(rnd<T>(v));
-                } else if (EPI == EPI_BIAS_RESID) {
-                    float *o = (float *)g.out + (size_t)row * g.ldo + col;
-                    *o = v + *o;
-                } else if (EPI == EPI_BIAS_F32) {
-                    ((float *)g.out)[(size_t)row * g.ldo + col] = v;
-                } else {   // EPI_PATCH
-                    const int b = row / g.tpi, t = row - b * g.tpi;
-                    const size_t orow = (size_t)row + b + 1;
-                    ((float *)g.out)[orow * g.ldo + col] = v + g.pos[(size_t)(t + 1) * g.ldo + col];
-                }
-            }
-        }
-    }
+    const bool full = (m0 + GBM <= g.M_real) && (n0 + GBN <= g.N);
+    if (full) epilogue16<T, EPI, 4, 4, true>(g, acc, m0 + wm * 64 + l15, n0 + wn * 64 + g4 * 4);
+    else epilogue16<T, EPI, 4, 4, false>(g, acc, m0 + wm * 64 + l15, n0 + wn * 64 + g4 * 4);
 }
 
 int gemm_tile_m() { return 256; }   // row padding of every activation buffer (ring kernel tile height)
@@ -1243,7 +1215,7 @@ const Tuning *tuning_for_device(int device) {
     t->gemm_skinny = getenv("VITX_GEMM_NOSKINNY") == nullptr;
     t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);      // r02: with the persistent ping-pong kernel the two-launch tail split costs 5 % of the step (profiles/r02_forward_sweeps.txt)
     t->gemm_balance = env_int("VITX_GEMM_BALANCE", 1);
-    t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : (env_int("VITX_PP_SCHED", 4) == 8 ? 8192 : 0);
+    t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : (env_int("VITX_PP_SCHED", 4) == 8 ? 8192 : (env_int("VITX_PP_SCHED", 4) == 32 ? 65536 : 0));
     t->group_m = env_int("VITX_GROUP_M", 0);
     t->ln_fuse = env_int("VITX_LN_FUSE", 1);
     t->pp_dbg = env_int("VITX_PP_DBG", 0);
