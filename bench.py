@@ -206,7 +206,7 @@ def main():
                     ptf, pmhz = binding.probe_mfma(local_rank, dt, 2, 150.0)
                     out["roofline"]["mfma_sustained_random_operands"] = {
                         "TFLOPs": round(ptf, 1), "shader_clock_MHz": round(pmhz), "frac_of_it": round(tf / ptf, 4),
-                        "what": "vitx_probe_mfma: 8 waves/CU of back-to-back v_mfma_f32_32x32x16 on register operands (uniform random values), ~150 ms; "
+                        "what": "vitx_probe_mfma: 8 waves/CU of back-to-back v_mfma_f32_16x16x32 (the GEMM kernels' instruction) on register operands (uniform random values), ~150 ms; "
                                 "the package sits at its 1400 W cap and the clock drops below the nominal 2400 MHz (zero-filled operands: ~2480 TFLOP/s)"}
                     out["mfma_sustained_frac_whole_forward"] = round(value / world * gflop / 1e3 / ptf, 4)
                 except Exception as e:      # the probe is informative only

@@ -171,7 +171,7 @@ typedef struct vitx_prof_entry {
     double busy_ms;       /* wall time during which >= 1 launch of this class was running (union over the
                              context's concurrent sub-batch streams); == total_ms on a single stream */
 } vitx_prof_entry;
-/* Matrix-pipe probe: back-to-back v_mfma_f32_32x32x16 on register operands on every CU for ~target_ms (no LDS, no memory).
+/* Matrix-pipe probe: back-to-back v_mfma_f32_16x16x32 (the instruction of the GEMM kernels) on register operands on every CU for ~target_ms (no LDS, no memory).
  * fill 0 = zero operands, 1 = constant, 2 = uniform random in [-1, 1).  Returns TFLOP/s and the shader clock the device actually ran
  * at.  MI355X is power-capped on random operands (bf16 ~1830 of the nominal 2517 TFLOP/s): the roofline bench.py reports carries
  * this measured ceiling next to the nominal peak. */

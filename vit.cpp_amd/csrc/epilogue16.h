@@ -102,4 +102,121 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][T
     }
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// The patch is written and read back by the same wave through different vector types: a compiler-level barrier keeps those
+// accesses in program order (the LDS itself executes one wave's operations in issue order -- verified in r02 with and without an
+// lgkmcnt(0) between the writes and the reads).
+__device__ __forceinline__ void pp_lds_fence() { asm volatile("" ::: "memory"); }
+
+// 16-byte buffer store followed by the wait states hipcc does not insert: with an SGPR soffset LLVM's hazard recognizer assumes
+// "store of more than 64 bits -> VALU overwrite of its data registers" cannot happen, but on gfx950 the very next VALU write DID
+// corrupt the stored dwords (r02: 0.7 % of the f32-epilogue outputs, 1 % of the GELU outputs, always the same lanes).
+template <int AUX = 0>      // AUX 16 = sc1 (write-through): the tile is handed to another workgroup inside the launch
+__device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(d, ro, voff, soff, AUX);
+    __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- full-tile epilogue through a wave-private 4 KiB LDS patch: whole-row stores, an EXACT number of vector-memory instructions.
+//   * the accumulators hold one ROW per lane: a store straight from them touches 16 different 128-byte lines per instruction and
+//     the texture-address path serialises on lines (the ring kernels lost 20-27 % to it when they first moved to 16-wide tiles).
+//     So each 32-row block goes through the patch: written in the MFMA layout, read back with 8 lanes per 128-byte row, stored as
+//     whole lines (8 lines per instruction).  Patch rows are 128 B; 16-byte slots are XOR-ed with (row & 7): conflict-free reads,
+//     <= 2-way writes.
+//   * every store is one buffer_store_dwordx4 issued unconditionally (16 * NB / 4 for 16-bit outputs, 8 * NB for f32), so a
+//     persistent kernel can skip over them with a counted vmcnt in the next tile's K loop instead of draining them.
+// The wave's block is (NB * 32) rows x 64 columns: acc[2 NB][4].  bq[u] = bias of columns 16 u + 4 g4 .. + 3.
+// voff = this lane's byte offset in row layout (row lane >> 3 of the wave's block, 16-byte piece lane & 7), soff = tile origin,
+// soff8 = 8 rows, all in bytes of the output type; ro = buffer resource of the output matrix.
+template <typename T, int EPI, int NB, int AUX = 0>
+__device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const f32x4 (&bq)[4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int rd_off = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);         // row layout: row (lane>>3) + 8t, 16-byte piece lane&7
+    pp_lds_fence();
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        typedef typename Pair<T>::v2 v2;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {                 // 32-row block i = tiles t = 2i, 2i + 1
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f32x4 v = acc[2 * i + tp][u] + bq[u];
+                    v2 p0 = round_pair<T>(v[0], v[1]), p1 = round_pair<T>(v[2], v[3]);
+                    if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
+                        const f32x2 y0 = gelu_tanh2(f32x2{(float)p0[0], (float)p0[1]}), y1 = gelu_tanh2(f32x2{(float)p1[0], (float)p1[1]});
+                        p0 = round_pair<T>(y0[0], y0[1]); p1 = round_pair<T>(y1[0], y1[1]);
+                    }
+                    // columns u * 16 + 4 g4 .. + 3 -> bytes u * 32 + 8 g4 of the 128-byte patch row: 16-byte slot 2u + (g4 >> 1), half g4 & 1
+                    *(u32x2 *)(patch + prow * 128 + (((2 * u + (g4 >> 1)) * 16) ^ x16) + (g4 & 1) * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+                }
+            }
+            pp_lds_fence();
+            u32x4 d[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = *(const u32x4 *)(patch + t * 1024 + rd_off);
+            pp_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pp_store_b128<AUX>(d[t], ro, voff, soff + (i * 4 + t) * soff8);
+        }
+    } else {       // f32 outputs: one 32 x 32 block (4 KiB) per pass
+        u32x4 res[2][4];                            // residual rows of the current and the next pass (loads run one pass ahead)
+        auto load_res = [&](int c, u32x4 (&dst)[4]) {
+            const int i = c >> 1, j = c & 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+        };
+        if constexpr (EPI == EPI_BIAS_RESID) load_res(0, res[0]);
+#pragma unroll
+        for (int c = 0; c < 2 * NB; ++c) {
+            const int i = c >> 1, j = c & 1;
+            if constexpr (EPI == EPI_BIAS_RESID) { if (c + 1 < 2 * NB) load_res(c + 1, res[(c + 1) & 1]); }
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) {        // columns (2j + uu) * 16 + 4 g4 of the wave = (uu * 16 + 4 g4) of this 32-column block: slot 4 uu + g4
+                    const f32x4 v = acc[2 * i + tp][2 * j + uu] + bq[2 * j + uu];
+                    *(f32x4 *)(patch + prow * 128 + (((4 * uu + g4) * 16) ^ x16)) = v;
+                }
+            }
+            pp_lds_fence();
+            f32x4 d[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = *(const f32x4 *)(patch + t * 1024 + rd_off);
+            pp_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
+                pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
+            }
+        }
+    }
+}
+
+// Whole-workgroup-tile wrapper for the kernels that stage through LDS they own after their K loop: the staged epilogue when the
+// tile is full and its byte offsets fit the 32-bit buffer addressing, epilogue16 otherwise (edge tiles, the patch embedding).
+// wave_row0 / wave_col0 = origin of the wave's (NB * 32) x 64 block inside the workgroup tile at (m0, n0).
+template <typename T, int EPI, int NB>
+__device__ __forceinline__ void epilogue16_tile(const GemmArgs &g, f32x4 (&acc)[2 * NB][4], bool full, int m0, int n0, int wave_row0, int wave_col0, char *patch, int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    if constexpr (EPI != EPI_PATCH) {
+        constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
+        if (full && (size_t)g.M * g.ldo * esz < 0xf0000000u && (g.ldo & 3) == 0) {
+            f32x4 bq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bq[u] = g.bias ? *(const f32x4 *)(g.bias + n0 + wave_col0 + u * 16 + g4 * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)0xffffffffu, 0x00020000);
+            const int voff = ((wave_row0 + (lane >> 3)) * g.ldo + wave_col0) * esz + (lane & 7) * 16;
+            epilogue16_staged<T, EPI, NB>(acc, bq, ro, patch, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
+            return;
+        }
+    }
+    if (full) epilogue16<T, EPI, 2 * NB, 4, true>(g, acc, m0 + wave_row0 + l15, n0 + wave_col0 + 4 * g4);
+    else epilogue16<T, EPI, 2 * NB, 4, false>(g, acc, m0 + wave_row0 + l15, n0 + wave_col0 + 4 * g4);
+}
+
 }  // namespace vitx

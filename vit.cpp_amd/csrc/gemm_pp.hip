@@ -28,6 +28,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "epilogue16.h"
 
 // Register cap of the kernel (hipcc doubles amdgpu_num_vgpr on gfx90a+: arch + accumulator halves, so 128 = all 256 registers of a
 // 2-waves-per-SIMD kernel).  r02 experiment: 116 (= 232) leaves 48 VGPRs per SIMD free, exactly one LayerNorm wave, so the other
@@ -116,22 +117,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs &g, f32x16 (&acc)[4][
 //     goes through a wave-private 4 KiB LDS patch (the 32 KiB the operand ring leaves free): written in the MFMA layout,
 //     read back with 8 lanes per 128-byte row, stored as whole lines (8 lines per instruction).
 //     Patch rows are 128 B; 16-byte slots are XOR-ed with (row & 7): conflict-free reads, <= 2-way writes.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-// The patch is written and read back by the same wave through different vector types: a compiler-level barrier keeps those
-// accesses in program order (the LDS itself executes one wave's operations in issue order -- verified in r02 with and without an
-// lgkmcnt(0) between the writes and the reads).
-__device__ __forceinline__ void pp_lds_fence() { asm volatile("" ::: "memory"); }
-
-// 16-byte buffer store followed by the wait states hipcc does not insert: with an SGPR soffset LLVM's hazard recognizer assumes
-// "store of more than 64 bits -> VALU overwrite of its data registers" cannot happen, but on gfx950 the very next VALU write DID
-// corrupt the stored dwords (r02: 0.7 % of the f32-epilogue outputs, 1 % of the GELU outputs, always the same lanes).
-template <int AUX = 0>      // AUX 16 = sc1 (write-through): the tile is handed to another workgroup inside the launch
-__device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(d, ro, voff, soff, AUX);
-    __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
-}
 template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
 
 template <typename T, int EPI, bool NOSTORE = false, int AUX = 0>
@@ -207,112 +192,6 @@ __device__ __forceinline__ void pp_epilogue_full(f32x16 (&acc)[4][2], __amdgpu_b
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
-                pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
-            }
-        }
-    }
-}
-
-// ---- the same two epilogues for the 16x16x32 accumulator layout (FLAGS 65536).  A wave's 128 x 64 block is 8 x 4 tiles of 16 x 16;
-// swapped products: lane (l15 = lane & 15, g4 = lane >> 4) holds row t * 16 + l15 and columns u * 16 + 4 g4 .. + 3 of tile (t, u).
-template <typename T, int EPI, bool FULL>
-__device__ __forceinline__ void pp16_epilogue(const GemmArgs &g, f32x4 (&acc)[8][4], int row0 /* m0 + wave row * 128 + l15 */, int ncol /* first column of the wave */, int g4) {
-    typedef typename Elem<T>::v4 v4;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int c = ncol + u * 16 + g4 * 4;
-        const f32x4 bv = *(const f32x4 *)(g.bias + c);                   // the bias buffer is padded to the N tile
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int row = row0 + t * 16;
-            const bool ok = FULL || (row < g.M_real && c < g.N);
-            const f32x4 v = acc[t][u] + bv;
-            if constexpr (EPI == EPI_BIAS) {
-                if (ok) *(v4 *)((T *)g.out + (size_t)row * g.ldo + c) = __builtin_convertvector(v, v4);
-            } else if constexpr (EPI == EPI_BIAS_GELU) {
-                const typename Pair<T>::v2 x01 = round_pair<T>(v[0], v[1]), x23 = round_pair<T>(v[2], v[3]);
-                const f32x2 y01 = gelu_tanh2(f32x2{(float)x01[0], (float)x01[1]}), y23 = gelu_tanh2(f32x2{(float)x23[0], (float)x23[1]});
-                const typename Pair<T>::v2 o01 = round_pair<T>(y01[0], y01[1]), o23 = round_pair<T>(y23[0], y23[1]);
-                if (ok) *(v4 *)((T *)g.out + (size_t)row * g.ldo + c) = v4{o01[0], o01[1], o23[0], o23[1]};
-            } else if constexpr (EPI == EPI_BIAS_RESID) {
-                if (ok) { f32x4 *p = (f32x4 *)((float *)g.out + (size_t)row * g.ldo + c); *p = v + *p; }
-            } else if constexpr (EPI == EPI_BIAS_F32) {
-                if (ok) *(f32x4 *)((float *)g.out + (size_t)row * g.ldo + c) = v;
-            } else {   // EPI_PATCH
-                if (ok) {
-                    const int b = row / g.tpi, tk = row - b * g.tpi;
-                    const f32x4 pe = *(const f32x4 *)(g.pos + (size_t)(tk + 1) * g.ldo + c);
-                    *(f32x4 *)((float *)g.out + ((size_t)row + b + 1) * g.ldo + c) = v + pe;
-                }
-            }
-        }
-    }
-}
-
-template <typename T, int EPI, int AUX = 0>
-__device__ __forceinline__ void pp16_epilogue_full(f32x4 (&acc)[8][4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane) {
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int rd_off = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);         // row layout: row (lane>>3) + 8t, 16-byte piece lane&7
-    f32x4 bq[4];                                                                            // bias of columns u * 16 + 4 g4 .. + 3 (staged into the patch by LDS-DMA)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bq[u] = *(const f32x4 *)(patch + u * 64 + g4 * 16);
-    pp_lds_fence();
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        typedef typename Pair<T>::v2 v2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                  // 32-row block i = tiles t = 2i, 2i + 1
-#pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f32x4 v = acc[2 * i + tp][u] + bq[u];
-                    v2 p0 = round_pair<T>(v[0], v[1]), p1 = round_pair<T>(v[2], v[3]);
-                    if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
-                        const f32x2 y0 = gelu_tanh2(f32x2{(float)p0[0], (float)p0[1]}), y1 = gelu_tanh2(f32x2{(float)p1[0], (float)p1[1]});
-                        p0 = round_pair<T>(y0[0], y0[1]); p1 = round_pair<T>(y1[0], y1[1]);
-                    }
-                    // columns u * 16 + 4 g4 .. + 3 -> bytes u * 32 + 8 g4 of the 128-byte patch row: 16-byte slot 2u + (g4 >> 1), half g4 & 1
-                    *(u32x2 *)(patch + prow * 128 + (((2 * u + (g4 >> 1)) * 16) ^ x16) + (g4 & 1) * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
-                }
-            }
-            pp_lds_fence();
-            u32x4 d[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) d[t] = *(const u32x4 *)(patch + t * 1024 + rd_off);
-            pp_lds_fence();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) pp_store_b128<AUX>(d[t], ro, voff, soff + (i * 4 + t) * soff8);
-        }
-    } else {       // f32 outputs: one 32 x 32 block (4 KiB) per pass
-        u32x4 res[2][4];
-        auto load_res = [&](int c, u32x4 (&dst)[4]) {
-            const int i = c >> 1, j = c & 1;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
-        };
-        if constexpr (EPI == EPI_BIAS_RESID) load_res(0, res[0]);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int i = c >> 1, j = c & 1;
-            if constexpr (EPI == EPI_BIAS_RESID) { if (c + 1 < 8) load_res(c + 1, res[(c + 1) & 1]); }
-#pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
-#pragma unroll
-                for (int uu = 0; uu < 2; ++uu) {        // columns (2j + uu) * 16 + 4 g4 of the wave = (uu * 16 + 4 g4) of this 32-column block: slot 4 uu + g4
-                    const f32x4 v = acc[2 * i + tp][2 * j + uu] + bq[2 * j + uu];
-                    *(f32x4 *)(patch + prow * 128 + (((4 * uu + g4) * 16) ^ x16)) = v;
-                }
-            }
-            pp_lds_fence();
-            f32x4 d[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) d[t] = *(const f32x4 *)(patch + t * 1024 + rd_off);
-            pp_lds_fence();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);
                 pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
             }
         }
@@ -684,12 +563,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             } else if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
                 constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
                 const int voff = ((wr * 128 + (lane >> 3)) * g.ldo + wc * 64) * esz + (lane & 7) * 16;
-                pp16_epilogue_full<T, EPI, (FLAGS & 32768) ? 16 : 0>(acc16, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
+                f32x4 bq[4];                       // bias of columns u * 16 + 4 g4 .. + 3, staged into the wave's patch by LDS-DMA during the K loop
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bq[u] = *(const f32x4 *)(smem + LDS + wave * 4096 + u * 64 + g4 * 16);
+                epilogue16_staged<T, EPI, 4, (FLAGS & 32768) ? 16 : 0>(acc16, bq, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
                 relaxed = true;
             } else {
                 const int row0 = m0 + wr * 128 + l15, ncol = n0 + wc * 64;
-                if (full) pp16_epilogue<T, EPI, true>(g, acc16, row0, ncol, g4);
-                else pp16_epilogue<T, EPI, false>(g, acc16, row0, ncol, g4);
+                if (full) epilogue16<T, EPI, 8, 4, true>(g, acc16, row0, ncol + 4 * g4);
+                else epilogue16<T, EPI, 8, 4, false>(g, acc16, row0, ncol + 4 * g4);
             }
         } else if constexpr ((FLAGS & 2048) != 0) {
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]), "v"(acc[0][1]), "v"(acc[1][1]), "v"(acc[2][1]), "v"(acc[3][1]));

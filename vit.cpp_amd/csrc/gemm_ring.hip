@@ -202,9 +202,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN == 4 && WMT * WNT > 8) ?
         }
         return;
     }
+    // the last slot's barrier has passed and nothing is in flight: the ring is free, every wave takes 4 KiB of it as its epilogue patch
+    static_assert(WNT == 2, "epilogue16_tile: 64 columns per wave");
     const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
-    if (full) epilogue16<T, EPI, 2 * WMT, 2 * WNT, true>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
-    else epilogue16<T, EPI, 2 * WMT, 2 * WNT, false>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
+    epilogue16_tile<T, EPI, WMT>(g, acc, full, m0, n0, wm * (WMT * 32), wn * (WNT * 32), smem + wave * 4096, lane);
 }
 
 // ---- persistent variant: one workgroup per CU walks tiles v = bid, bid + grid, ... and keeps ONE ring running
@@ -338,9 +339,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, (NWM * NWN * 64) / 256) void gemm_s
             for (int u = 0; u < 2 * WNT; ++u) acc[t][u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         for (int i = 0; i < nslots; i += 2) { slot(RI0{}, i); slot(RI1{}, i + 1); }     // nslots is even: the parity restarts with every tile
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) again, unconditionally and visible to hipcc (free: the last slot's wait drained everything)
+        // the ring already holds the next tile's first slots: the epilogue patches (4 KiB per wave) live behind it
         const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
-        if (full) epilogue16<T, EPI, 2 * WMT, 2 * WNT, true>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
-        else epilogue16<T, EPI, 2 * WMT, 2 * WNT, false>(g, acc, m0 + wm * (WMT * 32) + l15, n0 + wn * (WNT * 32) + 4 * g4);
+        epilogue16_tile<T, EPI, WMT>(g, acc, full, m0, n0, wm * (WMT * 32), wn * (WNT * 32), smem + NS * SLOT_BYTES + wave * 4096, lane);
     }
 }
 
@@ -371,8 +372,8 @@ static hipError_t launch_ring_inst(const GemmArgs &a, hipStream_t stream, bool p
 
 template <typename T, int EPI>
 static hipError_t launch_stream_inst(const GemmArgs &a, int n_cu, hipStream_t stream, bool prepare) {
-    constexpr int WMT = 4, WNT = 2, NWM = 2, NWN = 4, NS = 5, KS = 2;
-    constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32, lds = NS * (BM + BN) * 32 * KS;
+    constexpr int WMT = 4, WNT = 2, NWM = 2, NWN = 4, NS = 4, KS = 2;      // 4 slots of 32 KiB + 8 epilogue patches of 4 KiB = 160 KiB
+    constexpr int BM = NWM * WMT * 32, BN = NWN * WNT * 32, lds = NS * (BM + BN) * 32 * KS + NWM * NWN * 4096;
     if (prepare) return hipFuncSetAttribute((const void *)gemm_stream_kernel<T, EPI, WMT, WNT, NWM, NWN, NS, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     n_cu &= ~7;                                      // the tile walk keeps a workgroup on one XCD: grid must be a multiple of 8
     if (n_cu <= 0) n_cu = 256;
@@ -408,7 +409,7 @@ static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, int n_cu, h
 bool gemm_ring_supports(const GemmArgs &a, int cfg) {
     RingCfg c;
     if (!parse_cfg(cfg, c)) return false;
-    if (cfg == 945 && a.K < 16 * c.ks * c.ns) return false;
+    if (cfg == 945 && a.K < 16 * c.ks * 4) return false;      // the stream kernel's ring has 4 slots
     return a.M % (c.nwm * c.wmt * 32) == 0 && a.N_pad % (c.nwn * c.wnt * 32) == 0 && a.K % (32 * c.ks) == 0 && a.K >= 32 * c.ks;     // slot pairs: K % 64 == 0
 }
 

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    // every wave is past the last K-tile's barrier: the staging buffers are free, each wave takes 4 KiB as its epilogue patch
     const bool full = (m0 + GBM <= g.M_real) && (n0 + GBN <= g.N);
-    if (full) epilogue16<T, EPI, 4, 4, true>(g, acc, m0 + wm * 64 + l15, n0 + wn * 64 + g4 * 4);
-    else epilogue16<T, EPI, 4, 4, false>(g, acc, m0 + wm * 64 + l15, n0 + wn * 64 + g4 * 4);
+    epilogue16_tile<T, EPI, 2>(g, acc, full, m0, n0, wm * 64, wn * 64, smem + wave * 4096, lane);
 }
 
 int gemm_tile_m() { return 256; }   // row padding of every activation buffer (ring kernel tile height)

@@ -1,11 +1,12 @@
 // probe.hip -- measurement probes exported through the C ABI (nothing here is on the forward path).
 //
 // vitx_probe_mfma: what the matrix pipe of THIS device sustains under its power management, independent of any GEMM structure:
-// every CU runs 8 waves (2 per SIMD, like the GEMM kernels) of back-to-back v_mfma_f32_32x32x16 on register operands -- no LDS,
-// no memory, no barriers.  On MI355X the result depends on the operand VALUES: zero-filled operands run at the nominal clock
-// (~2480 TFLOP/s bf16), uniform random operands make the package hit its 1400 W cap and the clock drops to ~1.75 GHz
-// (~1830 TFLOP/s bf16, ~1690 f16; profiles/r02c/mfma_ceiling_and_power.txt).  bench.py reports the random-operand number next to
-// the nominal peak so the roofline fraction can be read against what the silicon can actually deliver on non-trivial data.
+// every CU runs 8 waves (2 per SIMD, like the GEMM kernels) of back-to-back v_mfma_f32_16x16x32 -- the instruction the GEMM kernels
+// use -- on register operands: no LDS, no memory, no barriers.  On MI355X the result depends on the operand VALUES: zero-filled
+// operands run at the nominal clock (~2480 TFLOP/s bf16), uniform random operands make the package hit its 1400 W cap and the
+// clock drops to ~1.98 GHz (~2030 TFLOP/s bf16; the 32x32x16 form costs 11 % more energy per flop: ~1.76 GHz, ~1815 TFLOP/s --
+// tools/mfma_ceiling.hip measures both, profiles/r02f/mfma_ceiling_both_shapes.txt).  bench.py reports the random-operand number
+// next to the nominal peak so the roofline fraction can be read against what the silicon can actually deliver on non-trivial data.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,23 +34,21 @@ __global__ __launch_bounds__(512, 2) void mfma_probe_kernel(ProbeOut *out, int i
             a[i][e] = (T)(fill == 0 ? 0.0f : (fill == 1 ? 0.5f : probe_unit(tid * 64 + i * 8 + e)));
             b[i][e] = (T)(fill == 0 ? 0.0f : (fill == 1 ? 0.5f : probe_unit(tid * 64 + 32 + i * 8 + e) * 0.05f));
         }
-    f32x16 acc[8];
+    f32x4 acc[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     __syncthreads();
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = Elem<T>::mfma(a[(i + k) & 3], b[i & 3], acc[i]);
+            for (int i = 0; i < 16; ++i) acc[i] = Elem<T>::mfma16(a[(i + k) & 3], b[i & 3], acc[i]);
     }
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
     if (threadIdx.x == 0) out[blockIdx.x] = ProbeOut{c1 - c0, r1 - r0, s, 0};
 }
 
@@ -84,7 +83,7 @@ extern "C" int vitx_probe_mfma(int device, int dtype, int fill, double target_ms
     double cyc = 0, rt = 0;
     for (int i = 0; i < n_cu; ++i) { cyc += (double)h[i].cycles; rt += (double)h[i].realtime; }
     delete[] h;
-    *tflops = 2.0 * 32 * 32 * 16 * (double)iters * 32 * 8 * n_cu / (ms * 1e-3) / 1e12;      // 32 MFMAs per iteration per wave, 8 waves per CU
+    *tflops = 2.0 * 16 * 16 * 32 * (double)iters * 64 * 8 * n_cu / (ms * 1e-3) / 1e12;      // 64 MFMAs per iteration per wave, 8 waves per CU
     if (clock_mhz) *clock_mhz = rt > 0 ? cyc / (rt / 100.0) : 0.0;                            // s_memrealtime ticks at 100 MHz
     (void)hipFree(d); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return VITX_OK;
