@@ -61,7 +61,9 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(Out *out, int iters) {
 
 // the same loop on v_mfma_f32_16x16x32 (4 accumulator registers per MFMA, 16 cycles each): 64 MFMAs per iteration = the same flops
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int FILL>
+// ORDER: which operand registers consecutive MFMAs share (operand-bus toggling): 0 both change every MFMA, 1 the first (A) operand is
+// held for 4 MFMAs, 2 the second (B) operand is held for 4, 3 both held (one register pair for everything)
+template <int FILL, int ORDER = 0>
 __global__ __launch_bounds__(512, 2) void mfma16_loop(Out *out, int iters) {
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
     bf16x8 a[4], b[4];
@@ -81,7 +83,11 @@ __global__ __launch_bounds__(512, 2) void mfma16_loop(Out *out, int iters) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + k) & 3], b[i & 3], acc[i], 0, 0, 0);
+            for (int i = 0; i < 16; ++i) {
+                const int ia = ORDER == 0 ? (i + k) & 3 : (ORDER == 1 ? (i >> 2) & 3 : (ORDER == 2 ? i & 3 : 0));
+                const int ib = ORDER == 0 ? i & 3 : (ORDER == 1 ? i & 3 : (ORDER == 2 ? (i >> 2) & 3 : 0));
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[ib], acc[i], 0, 0, 0);
+            }
     }
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.0f;
@@ -89,14 +95,14 @@ __global__ __launch_bounds__(512, 2) void mfma16_loop(Out *out, int iters) {
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
     if (threadIdx.x == 0) { Out o; o.cycles = c1 - c0; o.realtime = r1 - r0; o.mfmas = (unsigned long long)iters * 64; o.sink = s; out[blockIdx.x] = o; }
 }
-template <int FILL>
+template <int FILL, int ORDER = 0>
 static void run16(const char *name, int n_cu, double target_ms) {
     Out *d; CK(hipMalloc(&d, sizeof(Out) * n_cu));
     int iters = 2000;
     for (int pass = 0; pass < 2; ++pass) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((mfma16_loop<FILL>), dim3(n_cu), dim3(512), 0, 0, d, iters);
+        hipLaunchKernelGGL((mfma16_loop<FILL, ORDER>), dim3(n_cu), dim3(512), 0, 0, d, iters);
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (pass == 0) { iters = (int)(iters * target_ms / ms); if (iters < 100) iters = 100; continue; }
@@ -146,6 +152,9 @@ int main(int argc, char **argv) {
     run<half8, _Float16, 2, 0>("f16  uniform random", n_cu, ms);
     run16<0>("bf16 16x16x32 zero operands", n_cu, ms);
     run16<2>("bf16 16x16x32 uniform random", n_cu, ms);
+    run16<2, 1>("bf16 16x16x32 random, A held x4", n_cu, ms);
+    run16<2, 2>("bf16 16x16x32 random, B held x4", n_cu, ms);
+    run16<2, 3>("bf16 16x16x32 random, A and B held", n_cu, ms);
     run<bf16x8, __bf16, 2, 1>("bf16 random, s_sleep 1 / 32 MFMA", n_cu, ms);
     run<bf16x8, __bf16, 2, 4>("bf16 random, s_sleep 4 / 32 MFMA", n_cu, ms);
     run<bf16x8, __bf16, 2, 8>("bf16 random, s_sleep 8 / 32 MFMA", n_cu, ms);
