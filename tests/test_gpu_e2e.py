@@ -41,6 +41,23 @@ def test_forward_matches_oracle_f16(pkg, binding, oracle, torch_gpu, name, n):
     assert np.abs(logits - ref_logits).max() <= 2.5e-2
 
 
+@pytest.mark.parametrize("n", [3, 70])
+def test_odd_class_count_head(pkg, binding, oracle, torch_gpu, n):
+    """37 classes: the head GEMM's columns end inside a lane's group of four (epilogue16.h takes the per-element path there), at a
+    batch that runs the skinny ring tiles and one that runs the 128 x 256 ring tiles; rows of the big batch equal the small batch's."""
+    name = "vit_micro_c37_patch16_64"
+    path = pkg.synth.cached_synthetic(name, head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(n, 64, seed=11))
+    ref_logits, ref_probs = oracle.OracleModel(path).forward(imgs[:3], oracle.REF)
+    for dt, tol in ((binding.F16, TOL_PROB), (binding.BF16, 5e-3)):
+        probs, logits = _run(binding, path, imgs, dt)
+        assert probs.shape == (n, 37) and np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-4
+        assert np.abs(probs[:3] - ref_probs).max() <= tol
+        if n > 3:
+            p3, _ = _run(binding, path, imgs[:3], dt)
+            assert np.array_equal(probs[:3], p3)
+
+
 def test_forward_base_f16_vs_oracle_and_self_noise(pkg, binding, oracle, torch_gpu):
     """ViT-B/16 (the benchmarked model), 4 images.  Asserts 1e-3 on the head_scale=4 fixture and,
     on the peaked head_scale=8 fixture, that the GPU is no further from the oracle than 3x the

@@ -16,5 +16,7 @@ python tools/rocpd_summary.py $(find $out/prof $out/pmc1 $out/pmc2 -name "*.db" 
 python tools/hbm_traffic.py $(find $out/pmc1 -name "*.db" | head -1) $(find $out/pmc2 -name "*.db" | head -1) --commit "${COMMIT:-unknown}" --out $out/hbm_traffic.json > $out/hbm_traffic.log 2>&1
 ( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/profL -o fwd -- python $R/tools/prof_forward.py vit_large_patch16_384 128 3 bf16 > $R/$out/profL.log 2>&1 )
 python tools/rocpd_summary.py $(find $out/profL -name "*.db" | sort) > $out/rocprofv3_summary_large384.txt 2>&1
+# small-batch latency table: f16 file and q4_0 file (blocks in HBM), bf16 compute
+for ft in f16 q4_0; do for b in 1 8 32 64; do TF_FTYPE=$ft python tools/time_fwd.py $b vit_base_patch16_224 bf16 100 2>&1 | grep -v amdgpu; done; done > $out/small_batches.txt
 find $out -name "*.db" -size +20M -delete
 tail -c 600 $out/bench_bf16.json; echo; head -12 $out/rocprofv3_summary.txt

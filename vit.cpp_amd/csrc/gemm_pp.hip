@@ -4,13 +4,13 @@
 //   (ggml_mul_mat at /root/reference/vit.cpp:772,820,868,889,896 with the bias / GELU / residual / pos-embed ops fused).
 //
 // Structure (DESIGN.md "GEMM"):
-//   * 512 threads = 8 waves as 2(M) x 4(N); tile 256x256, BK = 64; each wave owns 128x64 of C as 4x2 MFMA 32x32x16
-//     accumulators.  One persistent workgroup per CU walks its tiles and keeps ONE operand stream running across tile
-//     boundaries.
+//   * 512 threads = 8 waves as 2(M) x 4(N); tile 256x256, BK = 64; each wave owns 128x64 of C as 8x4 accumulators of
+//     v_mfma_f32_16x16x32 (r02f; the 4x2 v_mfma_f32_32x32x16 form of r02a-e is FLAGS 65536: same cycles, 11 % more energy per
+//     flop).  One persistent workgroup per CU walks its tiles and keeps ONE operand stream running across tile boundaries.
 //   * The two wave rows (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART ("ping-pong"): while one
-//     group issues its 8 MFMAs of a phase, the other issues its LDS fragment reads and LDS-DMA for its own phase, so
+//     group issues the MFMAs of a phase (16 of 16x16x32), the other issues its LDS fragment reads and LDS-DMA for its own phase, so
 //     every SIMD always has one wave in the matrix pipe and one in the memory pipes.  s_setprio(1) brackets the MFMAs.
-//   * A K-tile is 4 phases, one C quadrant (64x32 per wave, K = 64 -> 8 MFMAs) each, in the snake order
+//   * A K-tile is 4 phases, one C quadrant (64x32 per wave, K = 64 -> 256 MFMA cycles) each, in the snake order
 //     C00, C01, C11, C10 so every operand fragment is read from LDS exactly once: 12 / 4 / 8 / 0 ds_read_b128.
 //   * LDS = 2 buffers x [A0 | A1 | B0 | B1] half-tiles of 16 KiB (128 rows x 128 B).  "A0" holds, for both wave rows,
 //     the first 64 of the wave's 128 rows (B0: for the four wave columns, the first 32 of the wave's 64 columns), so a

@@ -1,6 +1,6 @@
 // kernels.hip -- hand-written CDNA4 (gfx950) kernels of the ViT forward path.
 //
-// Written for MI355X only: 64-lane wavefronts, v_mfma_f32_32x32x16_{f16,bf16},
+// Written for MI355X only: 64-lane wavefronts, v_mfma_f32_16x16x32_{f16,bf16} (GEMMs) / v_mfma_f32_32x32x16 (attention),
 // global_load_lds (LDS-DMA) staging with a source-side XOR swizzle, 160 KiB LDS.
 // The math each kernel implements is the ggml op sequence vit_encode_image emits
 // (/root/reference/vit.cpp:718-941); per-kernel citations below.
@@ -21,7 +21,7 @@ namespace vitx {
 // ------------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] . W[N][K]^T  (ggml_mul_mat, vit.cpp:820,868,889,896,927 and the im2col GEMM
 // of ggml_conv_2d_sk_p0, vit.cpp:772) with the bias / GELU / residual / pos-embed epilogues fused.
-// 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles, LDS double buffer filled
+// 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of MFMA 16x16x32, LDS double buffer filled
 // by global_load_lds dwordx4 (one K-tile ahead).
 // ------------------------------------------------------------------------------------------------
 constexpr int GBM = 128, GBN = 128, GBK = 64;

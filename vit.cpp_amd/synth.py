@@ -20,6 +20,7 @@ from .ggml_file import HParams, write_model
 CONFIGS = {
     # name: (hidden, layers, heads, classes, patch, img)
     "vit_micro_patch16_64": (128, 2, 2, 10, 16, 64),       # test-only toy (N=17)
+    "vit_micro_c37_patch16_64": (128, 2, 2, 37, 16, 64),   # test-only toy with an ODD class count (the head GEMM's last column group is ragged)
     "vit_micro_patch8_224": (128, 2, 2, 10, 8, 224),       # test-only toy with the token count of the reference's default hparams (N=785)
     "vit_base_patch8_224": (768, 12, 12, 1000, 8, 224),    # the reference's default hparams (vit.h:22-28)
     "vit_tiny_patch16_224": (192, 12, 3, 1000, 16, 224),
