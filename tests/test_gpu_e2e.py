@@ -142,6 +142,56 @@ def test_errors_are_loud(pkg, binding, torch_gpu):
         binding.Context(model, device=99)
 
 
+@pytest.mark.parametrize("ftype", [1, 2])
+def test_small_batch_graph_replay_matches_direct_launches(pkg, binding, torch_gpu, tmp_path, ftype):
+    """With VITX_GRAPH=1 the single-stream forward is captured into a hipGraph the second time a call repeats (engine.cpp
+    forward_graph) and replayed from then on: replays must read the CURRENT contents of the input buffer, a different batch size or
+    output buffer must not hit the cached graph, and everything must equal a context that launches directly (the default).  f16 file and q4_0 file (the
+    per-layer dequant launches are part of the graph)."""
+    torch = torch_gpu
+    name = "vit_tiny_patch16_224"
+    path = str(tmp_path / "m.gguf")
+    pkg.synth.write_synthetic(path, name, ftype=ftype, head_scale=4.0)
+    a = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(4, 224, seed=1))
+    b = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(4, 224, seed=2))
+    model = binding.Model(path)
+    plain = binding.Context(model, max_batch=4)
+    want_a, want_b, want_a3 = plain.forward(a), plain.forward(b), plain.forward(a[:3])
+    plain.close()
+    os.environ["VITX_GRAPH"] = "1"                            # read at context creation
+    try:
+        ctx = binding.Context(model, max_batch=4)
+    finally:
+        del os.environ["VITX_GRAPH"]
+    d_img = torch.from_numpy(a).cuda()
+    d_probs = torch.zeros((4, 1000), device="cuda"); d_probs2 = torch.zeros((4, 1000), device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for it in range(5):                                   # call 0 direct, call 1 captures + launches, calls 2.. replay
+            d_probs.zero_()
+            ctx.forward_device(d_img.data_ptr(), 4, d_probs.data_ptr(), 0, s.cuda_stream)
+            s.synchronize()
+            assert np.array_equal(d_probs.cpu().numpy(), want_a), it
+        d_img.copy_(torch.from_numpy(b)); d_probs.zero_()     # same pointers, new pixels: the replay must see them
+        ctx.forward_device(d_img.data_ptr(), 4, d_probs.data_ptr(), 0, s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(d_probs.cpu().numpy(), want_b)
+        d_img.copy_(torch.from_numpy(a))
+        for it in range(3):                                   # another batch size and another output buffer: their own graphs
+            d_probs2.zero_()
+            ctx.forward_device(d_img.data_ptr(), 3, d_probs2.data_ptr(), 0, s.cuda_stream)
+            s.synchronize()
+            assert np.array_equal(d_probs2[:3].cpu().numpy(), want_a3), it
+            assert float(d_probs2[3].abs().max()) == 0.0
+        d_probs.zero_()
+        ctx.forward_device(d_img.data_ptr(), 4, d_probs.data_ptr(), 0, s.cuda_stream)     # back to the first key: still cached
+        s.synchronize()
+        assert np.array_equal(d_probs.cpu().numpy(), want_a)
+    for it in range(3):                                       # the host entry point goes through the same cache (its staging buffers are fixed)
+        assert np.array_equal(ctx.forward(b), want_b)
+    ctx.close(); model.close()
+
+
 def test_device_entry_point_with_torch_stream(pkg, binding, torch_gpu):
     """vitx_forward_device on torch-owned memory and torch's current stream."""
     torch = torch_gpu
