@@ -21,7 +21,7 @@ for n_img in (1, 4, 16, 64):
         out = torch.zeros((M, N), device="cuda", dtype=torch.float32 if epi >= 2 else tdt)
         s = torch.cuda.current_stream().cuda_stream
         row = f"{n_img:3d} img {name:5s} M={M:6d} N={N:5d} K={K:5d} {dtype}:"
-        for kernel in (0, 122, 129, 245, 945, 1):
+        for kernel in (0, 122, 245, 945, 1):
             call = lambda: L.vitx_op_gemm_ex(dt, epi, kernel, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), None, M, M - 59, N, K, 0, s)
             if call() != 0: row += f"  {kernel:>4d}: unsupported"; continue
             for _ in range(3): call()

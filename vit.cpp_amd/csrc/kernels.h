@@ -60,6 +60,7 @@ struct Tuning {
     int gemm_pp = 1;         // VITX_GEMM_PP=0: wide tiles through the r01 ring/stream kernels instead of the ping-pong kernel
     int gemm_stream = 1;     // VITX_GEMM_STREAM=0: one workgroup per tile (445) instead of the persistent 945 when the ring kernels run
     int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
+    int skinny_tiles = 128;  // VITX_SKINNY_TILES: 64x128 tiles (cfg 122) when fewer than this many 128x256 tiles exist (r02f: 64 -> 128, batches of 4-16 images)
     int gemm_split = 0;      // VITX_GEMM_SPLIT=1: tail rows of a partial round re-tiled 128x256 in a second launch (r01 default; off since the persistent kernel)
     int pp_flags = 0;        // VITX_PP_SCHED=2: the two-burst schedule of the ping-pong kernel (gemm_pp.hip FLAGS 4096) instead of the four-phase one
     int pp_dbg = 0;          // VITX_PP_DBG: ablation bits of the ping-pong kernel's fused LayerNorm (64 no row pass, 128 no hand-off at all)

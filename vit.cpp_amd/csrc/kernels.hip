@@ -170,7 +170,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream, 
 
 // Kernel selection (t.gemm_cfg overrides it for experiments).
 //   * >= 128 tiles of 256x256 and K % 128 == 0: the ping-pong persistent kernel (gemm_pp.hip);
-//   * otherwise 128x256 ring tiles, or the skinny 64x128 ring kernel when even those would leave most CUs idle
+//   * otherwise 128x256 ring tiles, or the skinny 64x128 ring kernel when those would leave half of the CUs idle
 //     (a handful of images: same K order per element, so results stay bit-identical across batch sizes);
 //   * anything the ring kernels cannot tile: the v1 128x128 kernel.
 static int wide_ring_cfg(const Tuning &t, const GemmArgs &a) { return (t.gemm_stream && gemm_ring_supports(a, 945)) ? 945 : 445; }
@@ -239,7 +239,7 @@ hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, h
             return launch_wide(t, dtype, epi, a, stream);
         }
         cfg = 245;
-        if (t.gemm_skinny && (long)(a.M / 128) * (a.N_pad / 256) < 64 && gemm_ring_supports(a, 122)) cfg = 122;
+        if (t.gemm_skinny && (long)(a.M / 128) * (a.N_pad / 256) < t.skinny_tiles && gemm_ring_supports(a, 122)) cfg = 122;
         if (gemm_ring_supports(a, cfg)) return launch_gemm_ring(t, dtype, epi, a, cfg, stream);
     }
     if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
@@ -1217,6 +1217,7 @@ const Tuning *tuning_for_device(int device) {
     t->gemm_balance = env_int("VITX_GEMM_BALANCE", 1);
     t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : (env_int("VITX_PP_SCHED", 4) == 8 ? 8192 : (env_int("VITX_PP_SCHED", 4) == 32 ? 65536 : 0));
     t->group_m = env_int("VITX_GROUP_M", 0);
+    t->skinny_tiles = env_int("VITX_SKINNY_TILES", 128);
     t->ln_fuse = env_int("VITX_LN_FUSE", 1);
     t->pp_dbg = env_int("VITX_PP_DBG", 0);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
