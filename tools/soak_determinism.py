@@ -1,20 +1,23 @@
 """Race hunt: repeat the forward many times and require bit-identical probabilities every time.
-python tools/soak_determinism.py [iters]   -- batches 256 / 203 / 64 / 8 / 1, fp16 and bf16, ViT-B/16."""
+python tools/soak_determinism.py [iters] [model]   -- batches 256 / 203 / 64 / 8 / 1, fp16 and bf16; default ViT-B/16
+(ViT-tiny, K = 192, additionally takes the persistent stream kernel for its wide shapes)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import _pkg; pkg = _pkg.load()
 from vitcpp_amd import binding as B
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-path = pkg.synth.cached_synthetic("vit_base_patch16_224", head_scale=8.0)
+name = sys.argv[2] if len(sys.argv) > 2 else "vit_base_patch16_224"
+path = pkg.synth.cached_synthetic(name, head_scale=8.0)
+hp = pkg.synth.hparams_for(name)
 m = B.Model(path)
 bad = 0
 for dt, dn in ((B.BF16, "bf16"), (B.F16, "f16")):
     for batch in (256, 203, 64, 8, 1):
         ctx = B.Context(m, 0, batch, dt)
         g = torch.Generator(device="cpu").manual_seed(batch)
-        imgs = torch.randn((batch, 224, 224, 3), generator=g).cuda()
-        probs = torch.empty((batch, 1000), device="cuda"); s = torch.cuda.current_stream().cuda_stream
+        imgs = torch.randn((batch, hp.img_size, hp.img_size, 3), generator=g).cuda()
+        probs = torch.empty((batch, hp.num_classes), device="cuda"); s = torch.cuda.current_stream().cuda_stream
         ctx.forward_device(imgs.data_ptr(), batch, probs.data_ptr(), 0, s); torch.cuda.synchronize()
         ref = probs.clone()
         n = iters if batch >= 64 else iters * 4
