@@ -61,6 +61,7 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(Out *out, int iters) {
 
 // the same loop on v_mfma_f32_16x16x32 (4 accumulator registers per MFMA, 16 cycles each): 64 MFMAs per iteration = the same flops
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// ORDER 4: as 0, with the accumulators in AGPRs (inline asm; hipcc's own choice for these kernels is the VGPR form)
 // ORDER: which operand registers consecutive MFMAs share (operand-bus toggling): 0 both change every MFMA, 1 the first (A) operand is
 // held for 4 MFMAs, 2 the second (B) operand is held for 4, 3 both held (one register pair for everything)
 template <int FILL, int ORDER = 0>
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(512, 2) void mfma16_loop(Out *out, int iters) {
             for (int i = 0; i < 16; ++i) {
                 const int ia = ORDER == 0 ? (i + k) & 3 : (ORDER == 1 ? (i >> 2) & 3 : (ORDER == 2 ? i & 3 : 0));
                 const int ib = ORDER == 0 ? i & 3 : (ORDER == 1 ? i & 3 : (ORDER == 2 ? (i >> 2) & 3 : 0));
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[ib], acc[i], 0, 0, 0);
+                if constexpr (ORDER == 4) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i + k) & 3]), "v"(b[i & 3]));
+                else acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ia], b[ib], acc[i], 0, 0, 0);
             }
     }
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -155,6 +157,8 @@ int main(int argc, char **argv) {
     run16<2, 1>("bf16 16x16x32 random, A held x4", n_cu, ms);
     run16<2, 2>("bf16 16x16x32 random, B held x4", n_cu, ms);
     run16<2, 3>("bf16 16x16x32 random, A and B held", n_cu, ms);
+    run16<2, 4>("bf16 16x16x32 random, acc in AGPRs", n_cu, ms);
+    run16<2, 0>("bf16 16x16x32 uniform random (again)", n_cu, ms);
     run<bf16x8, __bf16, 2, 1>("bf16 random, s_sleep 1 / 32 MFMA", n_cu, ms);
     run<bf16x8, __bf16, 2, 4>("bf16 random, s_sleep 4 / 32 MFMA", n_cu, ms);
     run<bf16x8, __bf16, 2, 8>("bf16 random, s_sleep 8 / 32 MFMA", n_cu, ms);
