@@ -67,6 +67,9 @@ const char *vitx_last_error(void);
  * shapes and byte sizes exactly where the reference does.  No GPU is touched. */
 int vitx_model_load(const char *path, vitx_model **out);
 void vitx_model_free(vitx_model *m);
+/* Unique id of this load within the process (> 0; 0 for NULL).  A context cache must key on this, not on the pointer: a freed model's
+ * address is routinely handed to the next vitx_model_load. */
+uint64_t vitx_model_uid(const vitx_model *m);
 int vitx_model_hparams(const vitx_model *m, vitx_hparams *out);
 int vitx_model_num_labels(const vitx_model *m);
 /* id2label lookup (vit.cpp:1065 uses .at(idx)); NULL when the id has no label. */
@@ -119,10 +122,23 @@ int vitx_vitstr_decode(const float *probs, int seq_len, int num_classes, int32_t
 /* Uploads the weights to `device` in `dtype` and allocates all activation scratch
  * for up to max_batch images once (the reference reallocates per call, vit.cpp:1009-1035).
  * Contexts for >= 16 images cut every batch into 2 contiguous sub-batches that run on two
- * internal HIP streams (env VITX_STREAMS=1..4 overrides); the cut is placed where the GEMM tile
- * counts of both parts fill whole rounds of CUs (110 + 146 for 256 ViT-B images on 256 CUs).
- * Results do not depend on the split: images are independent in every kernel. */
+ * internal HIP streams; the cut is placed where the GEMM tile counts of both parts fill whole
+ * rounds of CUs (110 + 146 for 256 ViT-B images on 256 CUs).
+ * Results do not depend on the split: images are independent in every kernel.
+ * The library reads NO environment variable: everything tunable is in vitx_ctx_options. */
 int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out);
+/* Options of a context; every field 0 = the default.  Set struct_size = sizeof(vitx_ctx_options) (lets the struct grow).
+ * All of them change HOW the forward is scheduled or where weights live, never what it computes. */
+typedef struct vitx_ctx_options {
+    int32_t struct_size;
+    int32_t streams;          /* sub-batch streams, 1..4 (default 2; contexts for fewer than 8 images per stream use 1) */
+    int32_t graph;            /* 1: cache the single-stream (small-batch) forward as a hipGraph, captured the second time a call repeats */
+    int32_t quant_on_host;    /* 1: expand block-quantised tensors once at upload (16 bits per weight in HBM) instead of keeping the blocks */
+    int32_t q4_fused_rows;    /* q4_0 GEMMs with at most this many rows expand the blocks inside the GEMM's LDS-fill path (default 0 = never) */
+    int32_t split_first;      /* with 2 streams: images of the first sub-batch (default 0 = the tile-round model decides) */
+    int32_t no_ln_fusion;     /* 1: every LayerNorm runs as its own kernel (default: norm2 / the next norm1 ride in the proj / fc2 GEMMs) */
+} vitx_ctx_options;
+int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype, const vitx_ctx_options *options, vitx_ctx **out);
 void vitx_ctx_free(vitx_ctx *c);
 int vitx_ctx_max_batch(const vitx_ctx *c);
 /* Probability rows per image that vitx_forward / vitx_forward_device write: 1 for a classifier ([n][num_classes]), 25 for a ViTSTR
@@ -190,8 +206,7 @@ int vitx_op_layernorm(int dtype, const void *d_x, const void *d_w, const void *d
  * M must be a multiple of 128 rows allocated; N, K multiples of 64. */
 int vitx_op_gemm(int dtype, int epi, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int M, int N, int K, void *stream);
 /* The same with an explicit kernel family, so every production GEMM variant can be checked against a numeric reference:
- *   kernel 0 = automatic (what the forward would pick for this shape), 1 = ping-pong persistent 256x256 kernel (gemm_pp.hip) with
- *   its four-phase K-tile schedule, 3 = the same kernel with the two-burst schedule (16-MFMA bursts, half the barriers),
+ *   kernel 0 = automatic (what the forward would pick for this shape), 1 = ping-pong persistent 256x256 kernel (gemm_pp.hip),
  *   945 / 445 = ring kernels with 256x256 tiles (persistent / one workgroup per tile), 245 = 128x256, 122 = skinny 64x128,
  *   2 = the automatic choice with the tail split forced on (rows of a partial round re-tiled 128x256 in a second launch).
  * Adds epi 4 (patch embedding, vit.cpp:772-797): out f32 [M + M/tpi + 1 rows] : row m -> row m + m/tpi + 1, + d_pos[(m % tpi) + 1][n];
@@ -202,7 +217,7 @@ int vitx_op_gemm_ex(int dtype, int epi, int kernel, const void *d_a, const void 
                     int M, int M_real, int N, int K, int tpi, void *stream);
 /* Block-quantised weights on the device (reference: ggml keeps q4_0 ... q8_0 tensors in block form through compute,
  * vit.cpp:384-414, 645-678).  A context built from a quantised file keeps the blocks in HBM (vitx_ctx_weight_bytes reports the
- * footprint; env VITX_QUANT_HOST=1 expands once on the host instead) and expands them on the device:
+ * footprint; vitx_ctx_options::quant_on_host expands once on the host instead) and expands them on the device:
  *   vitx_op_dequant : out[n_pad][K] (dtype) = expansion of N rows of K/32 blocks of type `qtype` (2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1,
  *                     8 q8_0) laid out as in the file -- except q4_0: d_blocks = nibble plane [N][K/32][16 bytes],
  *                     d_scales = f16 block scales [N][K/32] (d_scales is ignored for the other types); rows N..n_pad are zeros.
@@ -216,10 +231,11 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *d_a, const void *d_qs, const
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c);
 /* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
 int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
-/* kernel 0 = automatic, 1 = single-pass kernel (N <= 224, 257-288 or 577-608 tokens only), 2 = streaming two-pass kernel (any N),
+/* kernel 0 = automatic, 1 = single-pass kernel (N <= 224, 257-288 or 577-608 tokens only),
  * 3 = pipelined two-pass kernel (any N; LDS-DMA double buffering, transposed LDS reads), 4 = persistent single-pass kernel (193..224
  * tokens: one workgroup per CU walks the (image, head) items, the next item's K/V land by LDS-DMA while the current one is computed).
- * All of them give bit-identical results. */
+ * Kernels 1 and 3 give bit-identical results; kernel 4 issues v_mfma_f32_16x16x32 instead of 32x32x16 (same products, another
+ * accumulation grouping: equal within f32 summation noise). */
 int vitx_op_attention_ex(int dtype, int kernel, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* probs = softmax(logits) over num_classes with the reference's fp16 exp rounding (vit.cpp:931). */
 int vitx_op_softmax(const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);

@@ -113,6 +113,91 @@ def test_undecodable_input_is_an_error_not_a_crash(binding, tmp_path):
             pass
 
 
+def test_ppm_header_without_raster_is_rejected(binding):
+    """r02 advisor (high): a P6 file that ends right after maxval made `pos` step past the end, the unsigned `n - pos` wrapped and the
+    decoder copied w*h*3 bytes from beyond the buffer.  Every truncation point of a small valid file must be an error or a full image."""
+    rgb = np.arange(64 * 64 * 3, dtype=np.uint8)
+    for bad in (b"P6 64 64 255", b"P6\n64 64\n255", b"P6 64 64 255\n", b"P6 64 64 255\n" + bytes(100), b"P6 64 64 255X" + rgb.tobytes(), b"P6 64 64", b"P6"):
+        with pytest.raises(binding.VitxError):
+            binding.decode_image(bad)
+    good = b"P6 64 64 255\n" + rgb.tobytes()
+    assert binding.decode_image(good).shape == (64, 64, 3)
+    for cut in range(2, 40):
+        with pytest.raises(binding.VitxError):
+            binding.decode_image(good[:cut])
+
+
+def _adam7_png(img, depth=8, ctype=2):
+    """An Adam7-interlaced PNG written by hand (PIL cannot write one): filter type 0 on every row of every pass."""
+    import struct, zlib
+    h, w = img.shape[:2]
+    xo, yo, xs, ys = (0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)
+    raw = b""
+    for p in range(7):
+        sub = img[yo[p]::ys[p], xo[p]::xs[p]]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        for row in sub:
+            raw += b"\0" + (np.packbits(row).tobytes() if depth == 1 else row.tobytes())
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("shape", [(45, 67), (1, 1), (3, 2), (8, 8), (9, 17), (5, 1)])
+def test_png_adam7_interlaced(binding, shape):
+    """stbi_load de-interlaces Adam7 PNGs; so does the replacement (r02 advisor).  RGB, grey and 1-bit images of sizes where some passes are empty."""
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    rgb = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    assert np.array_equal(binding.decode_image(_adam7_png(rgb, 8, 2)), rgb)
+    grey = rgb[..., 0]
+    assert np.array_equal(binding.decode_image(_adam7_png(grey, 8, 0)), np.repeat(grey[..., None], 3, -1))
+    bits = (grey > 127).astype(np.uint8)
+    assert np.array_equal(binding.decode_image(_adam7_png(bits, 1, 0)), np.repeat((bits * 255)[..., None], 3, -1))
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(_adam7_png(rgb, 8, 2))).convert("RGB")), rgb)       # the hand-written encoder is a valid PNG
+
+
+def test_png_zlib_stream_cannot_expand_beyond_the_image(binding):
+    """A small IDAT that inflates to far more than (stride + 1) * height bytes is refused while inflating (r02 advisor: no output cap)."""
+    import struct, zlib
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data))
+    bomb = zlib.compress(bytes(64 << 20), 9)                   # 64 MiB of zeros in ~64 KiB
+    blob = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)) + chunk(b"IDAT", bomb) + chunk(b"IEND", b"")
+    with pytest.raises(binding.VitxError, match="expands beyond"):
+        binding.decode_image(blob)
+
+
+def test_jpeg_adobe_colour_spaces(binding):
+    """stbi_load(..., 3) converts Adobe CMYK / YCCK files (4 components, APP14 transform 0 / 2) to RGB with its x * k / 255 products and
+    takes 3-component files marked `transform 0` as plain RGB.  PIL writes CMYK JPEGs as inverted Adobe CMYK; the expected RGB is stb's
+    formula applied to PIL's own (lossy-decoded, inverted) planes."""
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    base = np.kron(rng.integers(0, 256, (6, 8, 4), dtype=np.uint8), np.ones((8, 8, 1), dtype=np.uint8))     # blocky: the DCT keeps it nearly exact
+    im = Image.fromarray(base, "CMYK")
+    buf = io.BytesIO(); im.save(buf, "JPEG", quality=100, subsampling=0)
+    got = binding.decode_image(buf.getvalue())
+    dec = np.asarray(Image.open(io.BytesIO(buf.getvalue())), dtype=np.int32)      # PIL hands back the CMYK planes (already un-inverted)
+    inv = 255 - dec                                                                # the bytes in the file (Adobe stores them inverted)
+    t = inv[..., :3] * inv[..., 3:4] + 128
+    want = (t + (t >> 8)) >> 8
+    assert got.shape == want.shape and np.abs(got.astype(np.int32) - want).max() <= 2
+    # a 3-component file with Adobe transform 0 and no JFIF marker is RGB: patch PIL's YCbCr output into that form
+    rgb = np.kron(rng.integers(0, 256, (4, 4, 3), dtype=np.uint8), np.ones((8, 8, 1), dtype=np.uint8))
+    buf = io.BytesIO(); Image.fromarray(rgb, "RGB").save(buf, "JPEG", quality=100, subsampling=0)
+    blob = buf.getvalue()
+    ycc = binding.decode_image(blob)
+    assert blob[2:4] == b"\xff\xe0"                                              # JFIF APP0 right after SOI
+    app0_len = int.from_bytes(blob[4:6], "big")
+    app14 = b"\xff\xee" + (14).to_bytes(2, "big") + b"Adobe" + bytes([0, 100, 0, 0, 0, 0, 0])   # transform 0
+    as_rgb = binding.decode_image(blob[:2] + app14 + blob[4 + app0_len:])
+    planes = np.asarray(Image.open(io.BytesIO(blob)).convert("YCbCr"))             # PIL: RGB -> YCbCr of the decoded image ~ the stored planes
+    assert not np.array_equal(as_rgb, ycc)
+    assert np.abs(as_rgb.astype(np.int32) - planes.astype(np.int32)).max() <= 3
+
+
 def test_reference_main_flow_builds_on_the_mirror_header(tmp_path):
     """examples/vit_main.cpp is /root/reference/main.cpp minus its ggml lines (:82-91, :110): it calls load_image_from_file,
     vit_image_preprocess, vit_model_load and vit_predict through vit.cpp_amd/vit.h and must link with plain g++."""

@@ -144,7 +144,7 @@ def test_errors_are_loud(pkg, binding, torch_gpu):
 
 @pytest.mark.parametrize("ftype", [1, 2])
 def test_small_batch_graph_replay_matches_direct_launches(pkg, binding, torch_gpu, tmp_path, ftype):
-    """With VITX_GRAPH=1 the single-stream forward is captured into a hipGraph the second time a call repeats (engine.cpp
+    """With vitx_ctx_options::graph the single-stream forward is captured into a hipGraph the second time a call repeats (engine.cpp
     forward_graph) and replayed from then on: replays must read the CURRENT contents of the input buffer, a different batch size or
     output buffer must not hit the cached graph, and everything must equal a context that launches directly (the default).  f16 file and q4_0 file (the
     per-layer dequant launches are part of the graph)."""
@@ -158,11 +158,7 @@ def test_small_batch_graph_replay_matches_direct_launches(pkg, binding, torch_gp
     plain = binding.Context(model, max_batch=4)
     want_a, want_b, want_a3 = plain.forward(a), plain.forward(b), plain.forward(a[:3])
     plain.close()
-    os.environ["VITX_GRAPH"] = "1"                            # read at context creation
-    try:
-        ctx = binding.Context(model, max_batch=4)
-    finally:
-        del os.environ["VITX_GRAPH"]
+    ctx = binding.Context(model, max_batch=4, graph=1)        # vitx_ctx_options::graph
     d_img = torch.from_numpy(a).cuda()
     d_probs = torch.zeros((4, 1000), device="cuda"); d_probs2 = torch.zeros((4, 1000), device="cuda")
     s = torch.cuda.Stream()

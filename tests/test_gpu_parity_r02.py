@@ -32,7 +32,7 @@ def _gelu_ref(x):
 # GEMM: all kernel families
 # ------------------------------------------------------------------------------------------------------------------
 M_BIG, TPI = 33280, 196            # 130 row tiles of 256; 169 whole "images" of 196 patch rows + a ragged rest
-KERNELS = [1, 3, 945, 445, 245, 122, 0, 2]          # vitx_op_gemm_ex kernel ids (1 / 3 = ping-pong kernel, four-phase / two-burst schedule)
+KERNELS = [1, 945, 445, 245, 122, 0, 2]          # vitx_op_gemm_ex kernel ids (1 = ping-pong kernel, 2 = automatic with the tail split)
 
 
 @pytest.mark.parametrize("dtype_name", ["f16", "bf16"])
@@ -104,7 +104,7 @@ def test_gemm_every_kernel_family_and_epilogue(binding, torch_gpu, kernel, dtype
 @pytest.mark.parametrize("dtype_name", ["f16", "bf16"])
 def test_gemm_kernel_families_are_bit_identical(binding, torch_gpu, dtype_name):
     """Every family consumes K in the same order with the same MFMA, so they agree BIT FOR BIT (this is what makes results
-    independent of the batch size, which decides the family): ping-pong (both K-tile schedules) vs ring 945 / 245 / 122 on all epilogues."""
+    independent of the batch size, which decides the family): ping-pong vs ring 945 / 245 / 122 on all epilogues."""
     torch = torch_gpu
     dt = binding.F16 if dtype_name == "f16" else binding.BF16
     tdt = torch.float16 if dtype_name == "f16" else torch.bfloat16
@@ -117,7 +117,7 @@ def test_gemm_kernel_families_are_bit_identical(binding, torch_gpu, dtype_name):
     L = binding.lib()
     for epi in (0, 1, 2, 3):
         outs = []
-        for kernel in (1, 3, 945, 245, 122):
+        for kernel in (1, 945, 245, 122):
             out = resid.clone() if epi >= 2 else torch.zeros((M, N), dtype=tdt, device="cuda")
             binding.check(L.vitx_op_gemm_ex(dt, epi, kernel, A.data_ptr(), W.data_ptr(), bias.data_ptr(), out.data_ptr(), None, M, M, N, K, 0, None))
             torch.cuda.synchronize()
@@ -312,11 +312,11 @@ def test_forward_large384_full_depth_vs_oracle(pkg, binding, oracle, torch_gpu):
 # ------------------------------------------------------------------------------------------------------------------
 # Attention for any token count (the reference's default hparams are patch 8 = 785 tokens, vit.h:22-28)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("kernel", [3])
 @pytest.mark.parametrize("n_img,N,H", [(1, 785, 2), (2, 300, 1), (1, 250, 3), (3, 225, 2), (1, 1025, 1), (2, 129, 2), (9, 65, 1), (2, 64, 3), (1, 1, 1)])
 def test_streaming_attention_any_token_count(binding, oracle, torch_gpu, n_img, N, H, kernel):
-    """Token counts the register-resident kernel is not instantiated for (or cannot hold) run a two-pass kernel: 2 = streaming,
-    3 = pipelined (LDS-DMA double buffering + transposed LDS reads; the automatic choice above 288 tokens)."""
+    """Token counts the register-resident kernel is not instantiated for (or cannot hold) run the pipelined two-pass kernel (3: LDS-DMA
+    double buffering + transposed LDS reads; the automatic choice above 288 tokens)."""
     torch = torch_gpu
     D = H * 64
     rng = np.random.default_rng(n_img * 100 + N + H)
@@ -332,14 +332,14 @@ def test_streaming_attention_any_token_count(binding, oracle, torch_gpu, n_img, 
 
 @pytest.mark.parametrize("N", [197, 577, 50, 257, 32])
 def test_streaming_attention_is_bit_identical_to_single_pass(binding, torch_gpu, N):
-    """Same products, same rounding points, key tiles summed in the same order: the three kernels agree bit for bit."""
+    """Same products, same rounding points, key tiles summed in the same order: the two kernel families agree bit for bit."""
     torch = torch_gpu
     n_img, H = 2, 3; D = H * 64
     g = torch.Generator(device="cuda").manual_seed(N)
     for tdt, dt in ((torch.float16, binding.F16), (torch.bfloat16, binding.BF16)):
         qkv = (torch.randn((n_img * N, 3 * D), device="cuda", generator=g) * 0.8).to(tdt)
         outs = []
-        for kernel in (1, 2, 3, 0):
+        for kernel in (1, 3):
             out = torch.zeros((n_img * N, D), dtype=tdt, device="cuda")
             binding.check(binding.lib().vitx_op_attention_ex(dt, kernel, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
             torch.cuda.synchronize(); outs.append(out)
@@ -425,63 +425,34 @@ def test_group_two_devices_match_one(pkg, binding, torch_gpu):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# LayerNorm fused into the residual GEMMs (r02c)
+# Persistent attention kernel (the benchmarked configuration's attention)
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype_name", ["f16", "bf16"])
-@pytest.mark.parametrize("name,n", [("vit_base_patch16_224", 37), ("vit_base_patch16_224", 256), ("vit_large_patch16_384", 9)])
-def test_layernorm_fused_into_residual_gemms_is_bit_identical(pkg, binding, torch_gpu, name, n, dtype_name):
-    """proj / fc2 on the ping-pong kernel normalise every 256-row block of the residual stream as soon as its last column tile is
-    stored (gemm_pp.hip, FLAGS 32768: cross-workgroup ticket + agent-scope acquire), replacing 2 of the 2 LayerNorm launches per layer.
-    Same sums in the same order as layernorm_kernel -> the whole forward is BIT-identical to VITX_LN_FUSE=0, with ragged last row
-    blocks (37 x 197 and 9 x 577 rows are not multiples of 256), two sub-batch streams (256 images) and both operand types; repeated
-    forwards on one context stay identical (the arrival counters reset themselves)."""
-    import os
-    torch = torch_gpu
-    dt = binding.F16 if dtype_name == "f16" else binding.BF16
-    path = pkg.synth.cached_synthetic(name, head_scale=8.0)
-    hp = pkg.synth.hparams_for(name)
-    g = torch.Generator(device="cuda").manual_seed(n)
-    imgs = torch.randn((n, hp.img_size, hp.img_size, 3), device="cuda", generator=g)
-    outs = {}
-    for fuse in ("0", "1"):                 # the fused path is opt-in (it is slower: profiles/r02c/layernorm_fusion.txt)
-        os.environ["VITX_LN_FUSE"] = fuse
-        try:
-            # VITX_LN_FUSE is read when the context is created
-            model = binding.Model(path)
-            ctx = binding.Context(model, device=0, max_batch=n, dtype=dt)
-        finally:
-            os.environ.pop("VITX_LN_FUSE", None)
-        res = []
-        for rep in range(3):
-            probs = torch.empty((n, hp.num_classes), device="cuda"); logits = torch.empty_like(probs)
-            ctx.forward_device(imgs.data_ptr(), n, probs.data_ptr(), logits.data_ptr(), 0)
-            ctx.synchronize()
-            res.append(logits.clone())
-        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
-        outs[fuse] = res[0]
-        ctx.close(); model.close()
-    assert torch.isfinite(outs["1"]).all()
-    assert torch.equal(outs["0"], outs["1"])
-
-
-@pytest.mark.parametrize("n_img,N,H", [(5, 197, 12), (64, 197, 12), (3, 224, 3), (7, 193, 2), (2, 200, 16)])
-def test_persistent_attention_is_bit_identical_to_single_pass(binding, torch_gpu, n_img, N, H):
+@pytest.mark.parametrize("n_img,N,H", [(5, 197, 12), (64, 197, 12), (3, 224, 3), (7, 193, 2), (2, 200, 16), (3, 209, 2), (2, 208, 1)])
+def test_persistent_attention_vs_single_pass_and_oracle(binding, oracle, torch_gpu, n_img, N, H):
     """Kernel 4 (193..224 tokens: persistent workgroups, the next (image, head) item's K/V arriving by LDS-DMA under the current item's
-    softmax, V^T through transposed LDS reads) computes the same products with the same rounding points in the same order as the
-    register-staged single-pass kernel: bit-identical in both operand types, with more items than workgroups (64 x 12 = 768 items
-    on 256 CUs), fewer (3 x 3), and with NaNs planted right behind the tensor (the padded keys 197..223 of the LAST image read
-    there: the buffer descriptor must return zeros)."""
+    softmax, V^T through transposed LDS reads, v_mfma_f32_16x16x32 products) computes the same products with the same rounding points
+    as the register-staged single-pass kernel (32x32x16 products) -- equal up to the f32 summation grouping, i.e. within one output ulp --
+    in both operand types, with more items than workgroups (64 x 12 = 768 items on 256 CUs), fewer (3 x 3), every token count it
+    accepts incl. 209..224 (14 live key tiles) and with NaNs planted right behind the tensor (the padded keys 197..223 of the LAST image
+    read there: the buffer descriptor must return zeros).  It is also checked against the oracle directly."""
     torch = torch_gpu
     D = H * 64
     g = torch.Generator(device="cuda").manual_seed(n_img * 1000 + N)
     rows = n_img * N
-    for tdt, dt in ((torch.float16, binding.F16), (torch.bfloat16, binding.BF16)):
+    for tdt, dt, ulp, omode in ((torch.float16, binding.F16, F16_ULP, oracle.GPU_F16), (torch.bfloat16, binding.BF16, BF16_ULP, oracle.GPU_BF16)):
         big = torch.full((rows + 64, 3 * D), float("nan"), device="cuda", dtype=tdt)
         big[:rows] = (torch.randn((rows, 3 * D), device="cuda", generator=g) * 0.8).to(tdt)
         outs = []
-        for kernel in (1, 4):
-            out = torch.zeros((rows, D), dtype=tdt, device="cuda")
+        for kernel in (binding.ATTN_SINGLE, binding.ATTN_PERSIST):
+            out = torch.full((rows + 8, D), 5.0, dtype=tdt, device="cuda")
             binding.check(binding.lib().vitx_op_attention_ex(dt, kernel, big.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
             torch.cuda.synchronize(); outs.append(out)
         assert torch.isfinite(outs[1].float()).all()
-        assert torch.equal(outs[0], outs[1])
+        assert float(outs[1][rows:].float().min()) == 5.0 and float(outs[1][rows:].float().max()) == 5.0     # nothing stored past the last token
+        a, b = outs[0][:rows].float(), outs[1][:rows].float()
+        assert float((a - b).abs().max()) <= 2 * ulp * float(a.abs().max())
+        assert float((a != b).float().mean()) < 0.2
+        if n_img <= 8:
+            ref = oracle.attention(big[:rows].float().cpu().numpy(), n_img, N, D, H, omode)
+            d = np.abs(b.cpu().numpy() - ref)
+            assert d.max() <= (3e-3 if dt == binding.F16 else 2.5e-2) and d.mean() <= (3e-4 if dt == binding.F16 else 2.5e-3)

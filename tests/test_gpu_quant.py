@@ -105,16 +105,10 @@ def test_op_gemm_q4_fused(pkg, binding, torch_gpu, M, N, K, epi, dtype):
     assert np.array_equal(got[M_real:], torch.from_numpy(untouched).to(out_t).float().numpy())     # rows beyond M_real are never stored
 
 
-def _ctx_forward(binding, path, imgs, dtype, max_batch, env):
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        model = binding.Model(path)
-        ctx = binding.Context(model, device=0, max_batch=max_batch, dtype=dtype)
-    finally:
-        for k, v in saved.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+def _ctx_forward(binding, path, imgs, dtype, max_batch, **options):
+    """options = fields of vitx_ctx_options (the library reads no environment variable)."""
+    model = binding.Model(path)
+    ctx = binding.Context(model, device=0, max_batch=max_batch, dtype=dtype, **options)
     probs, logits = ctx.forward(imgs, want_logits=True)
     wb = ctx.weight_bytes()
     ctx.close(); model.close()
@@ -123,20 +117,20 @@ def _ctx_forward(binding, path, imgs, dtype, max_batch, env):
 
 @pytest.mark.parametrize("ftype,ratio", [(2, 0.34), (3, 0.33), (6, 0.36), (7, 0.39), (8, 0.55)])
 def test_quantised_context_keeps_blocks_in_hbm(pkg, binding, oracle, torch_gpu, tmp_path, ftype, ratio):
-    """Device-resident blocks vs expand-at-upload (VITX_QUANT_HOST=1): the just-in-time expansion feeds the SAME GEMM kernels
+    """Device-resident blocks vs expand-at-upload (vitx_ctx_options::quant_on_host): the just-in-time expansion feeds the SAME GEMM kernels
     the same operand bits -> bit-identical logits; the fused q4_0 GEMM only changes the summation order; both within 1e-3 of the
     oracle on the same dequantised weights (quant_act=0, as in test_gpu_e2e.test_quantised_file_runs_dequantised)."""
     name = "vit_tiny_patch16_224"
     p = str(tmp_path / "q.gguf")
     pkg.synth.write_synthetic(p, name, ftype=ftype, head_scale=4.0)
     imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(24, 224))
-    host_p, host_l, host_b = _ctx_forward(binding, p, imgs, binding.F16, 24, {"VITX_QUANT_HOST": "1"})
-    jit_p, jit_l, jit_b = _ctx_forward(binding, p, imgs, binding.F16, 24, {"VITX_Q4_FUSED_ROWS": "0"})          # every matrix expanded just in time
+    host_p, host_l, host_b = _ctx_forward(binding, p, imgs, binding.F16, 24, quant_on_host=1)
+    jit_p, jit_l, jit_b = _ctx_forward(binding, p, imgs, binding.F16, 24, q4_fused_rows=0)          # every matrix expanded just in time
     assert np.array_equal(jit_l, host_l) and np.array_equal(jit_p, host_p)
     # the patch-embedding kernel stays f16 in a quantised file (4-D tensor, quantize.cpp:207-223), so the ratio is a little above bits/16
     assert jit_b <= ratio * host_b, (jit_b, host_b)
     if ftype == 2:
-        fus_p, fus_l, fus_b = _ctx_forward(binding, p, imgs[:3], binding.F16, 3, {"VITX_Q4_FUSED_ROWS": "4096"})  # 3 images: 768 rows -> fused kernel
+        fus_p, fus_l, fus_b = _ctx_forward(binding, p, imgs[:3], binding.F16, 3, q4_fused_rows=4096)  # 3 images: 768 rows -> fused kernel
         assert fus_b == jit_b
         assert np.abs(fus_p - host_p[:3]).max() <= 2e-4
         _, want = oracle.OracleModel(p).forward(imgs[:3], dataclasses.replace(oracle.REF, quant_act=0))
@@ -152,7 +146,7 @@ def test_q4_0_base_model_bf16_wide_path(pkg, binding, torch_gpu, tmp_path):
     p = str(tmp_path / "b_q4_0.gguf")
     binding.quantize_file(src, p, 2)
     imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(32, 224))
-    host_p, host_l, host_b = _ctx_forward(binding, p, imgs, binding.BF16, 32, {"VITX_QUANT_HOST": "1"})
-    dev_p, dev_l, dev_b = _ctx_forward(binding, p, imgs, binding.BF16, 32, {"VITX_Q4_FUSED_ROWS": "0"})
+    host_p, host_l, host_b = _ctx_forward(binding, p, imgs, binding.BF16, 32, quant_on_host=1)
+    dev_p, dev_l, dev_b = _ctx_forward(binding, p, imgs, binding.BF16, 32, q4_fused_rows=0)
     assert np.array_equal(dev_l, host_l)
     assert dev_b < 0.30 * host_b

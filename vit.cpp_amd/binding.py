@@ -14,17 +14,19 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VITX_LIB") or os.path.join(_HERE, "libvitx.so")   # VITX_LIB: development override (A/B builds)
+# VITX_LIB: development override (the -DVITX_LAB laboratory build, A/B builds).  bench.py marks its line invalid when it is set.
+LIB_PATH = os.environ.get("VITX_LIB") or os.path.join(_HERE, "libvitx.so")
 
 F16, BF16 = 0, 1
 BICUBIC, BILINEAR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH = 0, 1, 2, 3, 4
-GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT, GEMM_PP_TWO_BURST = 0, 1, 2, 3          # vitx_op_gemm_ex `kernel` (or a ring configuration: 945, 445, 245, 122)
+GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT = 0, 1, 2          # vitx_op_gemm_ex `kernel` (or a ring configuration: 945, 445, 245, 122)
+ATTN_AUTO, ATTN_SINGLE, ATTN_FLOW, ATTN_PERSIST = 0, 1, 3, 4   # vitx_op_attention_ex `kernel`
 
 EXPORTS = [
-    "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_hparams", "vitx_model_num_labels",
+    "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_uid", "vitx_model_hparams", "vitx_model_num_labels",
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_image_load", "vitx_image_decode", "vitx_image_free", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
-    "vitx_ctx_create", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
+    "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_probe_mfma",
     "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
@@ -34,6 +36,11 @@ EXPORTS = [
 class HParams(C.Structure):
     _fields_ = [("hidden_size", C.c_int32), ("num_hidden_layers", C.c_int32), ("num_attention_heads", C.c_int32), ("num_classes", C.c_int32),
                 ("patch_size", C.c_int32), ("img_size", C.c_int32), ("ftype", C.c_int32), ("eps", C.c_float)]
+
+
+class CtxOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("streams", C.c_int32), ("graph", C.c_int32), ("quant_on_host", C.c_int32), ("q4_fused_rows", C.c_int32),
+                ("split_first", C.c_int32), ("no_ln_fusion", C.c_int32)]
 
 
 class ProfEntry(C.Structure):
@@ -78,6 +85,7 @@ def lib():
         L.vitx_preprocess_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, ip, C.POINTER(C.c_float)]
         L.vitx_preprocess_u8_device.argtypes = [vp, ip, ip, ip, ip, ip, vp, vp]
         L.vitx_ctx_create.argtypes = [vp, ip, ip, ip, C.POINTER(vp)]
+        L.vitx_ctx_create_ex.argtypes = [vp, ip, ip, ip, C.POINTER(CtxOptions), C.POINTER(vp)]
         L.vitx_ctx_free.argtypes = [vp]
         L.vitx_ctx_max_batch.argtypes = [vp]
         L.vitx_forward.argtypes = [vp, C.POINTER(C.c_float), ip, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -217,13 +225,27 @@ def preprocess_device(d_u8: int, n: int, nx: int, ny: int, img_size: int, d_out:
     check(lib().vitx_preprocess_u8_device(d_u8, n, nx, ny, img_size, interp, d_out, stream or None), "vitx_preprocess_u8_device")
 
 
+def _check_image_shape(model: "Model", x: np.ndarray) -> None:
+    """[n, S, S, 3] for a classifier, [n, S, S] (one grey plane) for a ViTSTR file: the C ABI reads n * S * S * in_channels floats."""
+    S = model.img_size
+    want = (S, S, 3) if model.in_channels == 3 else (S, S)
+    if x.ndim != 1 + len(want) or tuple(x.shape[1:]) != want:
+        raise ValueError(f"images must be [n, {', '.join(map(str, want))}] for this model, got {tuple(x.shape)}")
+
+
 class Context:
     """Per-(thread, GPU) execution context (vit_state): weights in HBM + activation scratch."""
 
-    def __init__(self, model: Model, device: int = 0, max_batch: int = 1, dtype: int = F16):
+    def __init__(self, model: Model, device: int = 0, max_batch: int = 1, dtype: int = F16, **options):
+        """options: the fields of vitx_ctx_options (streams, graph, quant_on_host, q4_fused_rows, split_first, no_ln_fusion)."""
         self.model = model; self.device = device; self.max_batch = max_batch; self.dtype = dtype
         self._h = C.c_void_p()
-        check(lib().vitx_ctx_create(model._h, device, max_batch, dtype, C.byref(self._h)), "vitx_ctx_create")
+        opt = CtxOptions(struct_size=C.sizeof(CtxOptions))
+        for k, v in options.items():
+            if k not in dict(CtxOptions._fields_) or k == "struct_size":
+                raise TypeError(f"unknown context option {k!r}")
+            setattr(opt, k, int(v))
+        check(lib().vitx_ctx_create_ex(model._h, device, max_batch, dtype, C.byref(opt), C.byref(self._h)), "vitx_ctx_create_ex")
 
     def close(self):
         if getattr(self, "_h", None) and self._h:
@@ -238,6 +260,7 @@ class Context:
     def forward(self, imgs_hwc: np.ndarray, want_logits: bool = False):
         """Host arrays in/out (copies + sync): [n,S,S,3] f32 -> probs [n,C] (and logits)."""
         x = np.ascontiguousarray(imgs_hwc, np.float32); n = x.shape[0]
+        _check_image_shape(self.model, x)
         R = self.model.seq_len                      # ViTSTR: [n, S, S] grey in, [n, 25, C] out
         probs = np.empty((n, self.model.num_classes) if R == 0 else (n, R, self.model.num_classes), np.float32)
         logits = np.empty_like(probs) if want_logits else None

@@ -63,6 +63,40 @@ __device__ __forceinline__ f32x2 gelu_tanh2(f32x2 x) {
     return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
+// fc1 epilogue activation of two adjacent outputs (ggml_gelu through the fp16 table, /root/reference/vit.cpp:893).
+//   F16 (parity mode): the table's semantics -- argument rounded to fp16, result rounded to fp16.
+//   BF16 (the dtype BASELINE names): there is no bf16 rounding point in the reference to reproduce, so the argument stays f32 and only
+//   the stored value is rounded (it is the next GEMM's operand): one convert and two unpacks per pair less, same tolerance band.
+template <typename T> __device__ __forceinline__ typename Pair<T>::v2 gelu_out_pair(float v0, float v1);
+template <> __device__ __forceinline__ Pair<_Float16>::v2 gelu_out_pair<_Float16>(float v0, float v1) {
+    const Pair<_Float16>::v2 p = round_pair<_Float16>(v0, v1);
+    const f32x2 y = gelu_tanh2(f32x2{(float)p[0], (float)p[1]});
+    return round_pair<_Float16>(y[0], y[1]);
+}
+template <> __device__ __forceinline__ Pair<__bf16>::v2 gelu_out_pair<__bf16>(float v0, float v1) {
+    const f32x2 y = gelu_tanh2(f32x2{v0, v1});
+    return round_pair<__bf16>(y[0], y[1]);
+}
+
+// Softmax numerators of the attention kernels for two adjacent keys (ggml_soft_max, /root/reference/vit.cpp:856).
+//   F16 (parity mode): e = round(exp(round(s/8 - max/8))) -- the fp16 exp table's semantics; nmx = -max * kScale, kScale = 1/8 (exact).
+//   BF16: e = round_bf16(exp2(s * log2(e)/8 - max * log2(e)/8)): one fma and one v_exp_f32 per key, no rounded exponent.
+template <typename T> struct AttnExp;
+template <> struct AttnExp<_Float16> {
+    static constexpr float kScale = 0.125f;
+    static __device__ __forceinline__ Pair<_Float16>::v2 pair(float s0, float s1, float nmx) {
+        const Pair<_Float16>::v2 dh = round_pair<_Float16>(__builtin_fmaf(s0, 0.125f, nmx), __builtin_fmaf(s1, 0.125f, nmx));
+        const f32x2 t = f32x2{(float)dh[0], (float)dh[1]} * f32x2{1.44269504f, 1.44269504f};
+        return round_pair<_Float16>(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
+    }
+};
+template <> struct AttnExp<__bf16> {
+    static constexpr float kScale = 0.125f * 1.44269504088896340736f;
+    static __device__ __forceinline__ Pair<__bf16>::v2 pair(float s0, float s1, float nmx) {
+        return round_pair<__bf16>(__builtin_amdgcn_exp2f(__builtin_fmaf(s0, kScale, nmx)), __builtin_amdgcn_exp2f(__builtin_fmaf(s1, kScale, nmx)));
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // LDS tile image shared by the GEMM and attention kernels: rows of 64 elements (128 B = 8 slots of
 // 16 B).  Two rows form one 256-B bank line; the 16 slots of a line are XOR-ed with (line & 15) so a

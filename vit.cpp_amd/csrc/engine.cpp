@@ -64,9 +64,10 @@ struct vitx_ctx {
     int R = 1;                           // probability rows per image: 1 (cls token) or 25 (ViTSTR: tokens 0..24, vitstr.cpp:864-904)
     int tm = 128, tn = 128;
     const Tuning *tune = nullptr;        // per-device launch parameters (CU count, kernel selection), immutable
-    int split_override[4] = {0, 0, 0, 0};  // VITX_SPLIT, parsed at creation
-    bool slices_serial = false;          // VITX_SLICES_SERIAL, parsed at creation
-    int skip = 0;                        // VITX_SKIP (upper-bound experiments only; results are garbage): 1 = no attention, 2 = no per-layer LayerNorm
+    int split_first = 0;                 // vitx_ctx_options::split_first: images of the first of two sub-batches (0 = the tile-round model)
+#ifdef VITX_LAB
+    int skip = 0;                        // VITX_SKIP (upper-bound experiments; results are garbage): 1 = no attention, 2 = no per-layer LayerNorm
+#endif
     hipStream_t stream = nullptr;
     std::vector<void *> allocs;
     // weights
@@ -74,16 +75,12 @@ struct vitx_ctx {
     void *pe_w = nullptr, *head_w = nullptr;
     QuantW head_q;
     std::vector<LayerW> layers;
-    // quantised files: VITX_QUANT_HOST=1 restores the r01 behaviour (expand once on the host at upload, 16 bits per weight in HBM)
+    // quantised files: vitx_ctx_options::quant_on_host restores the r01 behaviour (expand once on the host at upload, 16 bits per weight in HBM)
     bool quant_on_device = true;
-    // q4_0 GEMMs with at most this many rows expand the blocks inside the GEMM's LDS-fill path (VITX_Q4_FUSED_ROWS).  0 = never: measured
-    // on ViT-B (profiles/r02c_quant.txt) the 128x128-tile fused kernel loses to "expand the layer just in time, then the skinny ring
+    // q4_0 GEMMs with at most this many rows expand the blocks inside the GEMM's LDS-fill path (vitx_ctx_options::q4_fused_rows).  0 = never:
+    // measured on ViT-B (profiles/r02c_quant.txt) the 128x128-tile fused kernel loses to "expand the layer just in time, then the skinny ring
     // kernels" at every batch size (batch 1: 1.75 vs 1.06 ms, batch 8: 2.15 vs 1.33 ms), so it is an option, not the default.
     int q4_fused_rows = 0;
-    // VITX_LN_FUSE=1 (read at context creation): norm2 / the next layer's norm1 ride in the proj / fc2 GEMMs on the ping-pong kernel
-    // (gemm_pp.hip FLAGS 32768).  Bit-identical and tested, but OFF by default: measured 13.3 vs 10.5 ms per ViT-B batch-256 forward
-    // (profiles/r02c/layernorm_fusion.txt) -- the hand-off itself is free, the row pass of a 256-row block on ONE workgroup is not.
-    bool ln_fuse = false;
     size_t weight_bytes = 0;             // device bytes held by weight matrices (vitx_ctx_weight_bytes)
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
@@ -95,7 +92,6 @@ struct vitx_ctx {
         void *QKV = nullptr;         // [Mpad][3D]
         void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
         void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
-        int *ln_cnt = nullptr;       // [Mpad / 256] arrival counters of the LayerNorm fused into the proj / fc2 GEMMs (gemm_pp.hip)
         void *Wq[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};   // just-in-time expansion of the current layer's quantised matrices
         void *Wq_head = nullptr;
         float *logits = nullptr;     // [Bpad][C_pad]
@@ -112,7 +108,7 @@ struct vitx_ctx {
     // residual-stream trace (vitx_trace_enable)
     std::vector<int> trace_ids;
     float *trace_buf = nullptr;  // [L + 1][n_ids][N][D]
-    // hipGraph cache of the single-stream (small-batch) forward, opt-in (VITX_GRAPH=1).  Key = (images, batch, outputs): the graph
+    // hipGraph cache of the single-stream (small-batch) forward, opt-in (vitx_ctx_options::graph).  Key = (images, batch, outputs): the graph
     // bakes the pointers in.  An entry is captured the second time in a row its key is seen (one-off calls are never captured).
     // Measured (profiles/r02f/hipgraph_small_batch.txt): replaying the ~100 dependent launches as a graph takes the enqueue work off
     // the host thread but does not shorten the forward -- ViT-B batch 1: 0.874 vs 0.867 ms, batch 8: 1.141 vs 1.136 ms.  The chain is
@@ -234,18 +230,10 @@ struct ProfScope {
 
 // `fused` != nullptr: W is that q4_0 matrix and the GEMM expands the blocks in its own LDS-fill path (small batches).
 int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
-         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr,
-         const GemmArgs *ln = nullptr /* ln_out / ln_cnt / ln_w / ln_b / ln_eps: the LayerNorm that follows this GEMM */, bool *ln_fused = nullptr) {
+         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr) {
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
     a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
-    if (ln_fused) *ln_fused = false;
-    // the LayerNorm of the output rows rides in the GEMM when the ping-pong kernel takes it in one launch (never while profiling: the
-    // per-kernel event times are meant to be comparable across builds, and a fused launch would be booked under the GEMM class alone)
-    if (ln && ln_fused && !fused && epi == EPI_BIAS_RESID && c->ln_fuse && !c->prof_on && gemm_can_fuse_layernorm(tune, a)) {
-        a.ln_out = ln->ln_out; a.ln_cnt = ln->ln_cnt; a.ln_w = ln->ln_w; a.ln_b = ln->ln_b; a.ln_eps = ln->ln_eps;
-        *ln_fused = true;
-    }
     double bytes = (double)M_real * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
     ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
@@ -262,9 +250,17 @@ int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const
 
 extern "C" {
 
-int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out) {
+int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out) { return vitx_ctx_create_ex(m, device, max_batch, dtype, nullptr, out); }
+
+int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype, const vitx_ctx_options *opt_in, vitx_ctx **out) {
     if (!m || !out || max_batch <= 0 || (dtype != VITX_F16 && dtype != VITX_BF16)) { set_error("vitx_ctx_create: invalid argument"); return VITX_ERR_ARG; }
     *out = nullptr;
+    vitx_ctx_options opt{};                   // all zero = every default
+    if (opt_in) {
+        if (opt_in->struct_size < 8 || opt_in->struct_size > (int)sizeof(vitx_ctx_options)) { set_error("vitx_ctx_create_ex: options.struct_size %d is not a size this library knows", opt_in->struct_size); return VITX_ERR_ARG; }
+        memcpy(&opt, opt_in, (size_t)opt_in->struct_size);
+        if (opt.streams < 0 || opt.streams > 4 || opt.q4_fused_rows < 0 || opt.split_first < 0) { set_error("vitx_ctx_create_ex: option out of range"); return VITX_ERR_ARG; }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("vitx_ctx_create: no HIP device available (this engine has no CPU fallback)"); return VITX_ERR_HIP; }
     if (device < 0 || device >= ndev) { set_error("vitx_ctx_create: device %d out of range (%d devices)", device, ndev); return VITX_ERR_ARG; }
@@ -289,16 +285,14 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     if (!layernorm_supports(c->D)) { set_error("vitx_ctx_create: hidden_size %d has no LayerNorm instantiation (64, 128, 192, 256, 384, 512, 768, 1024, 1280, 1536)", c->D); return VITX_ERR_UNSUPPORTED; }
     c->tune = tuning_for_device(device);
     if (!c->tune) { set_error("vitx_ctx_create: kernel bring-up on device %d failed: %s", device, hipGetErrorString(hipGetLastError())); return VITX_ERR_HIP; }
-    if (const char *e = getenv("VITX_SPLIT")) {          // experiments: "110" or "110,110" = sizes of the first nslices-1 sub-batches
-        int i = 0;
-        for (const char *p = e; i < 3 && *p; ++i) { c->split_override[i] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
-    }
-    c->slices_serial = getenv("VITX_SLICES_SERIAL") != nullptr;
-    c->quant_on_device = getenv("VITX_QUANT_HOST") == nullptr;
-    if (const char *e = getenv("VITX_Q4_FUSED_ROWS")) c->q4_fused_rows = atoi(e);
-    if (const char *e = getenv("VITX_LN_FUSE")) c->ln_fuse = atoi(e) != 0;
-    if (const char *e = getenv("VITX_GRAPH")) c->graphs_on = atoi(e) != 0;
-    if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);     // for rocprofv3 runs that should match the profiled steps
+    c->split_first = opt.split_first;
+    c->quant_on_device = !opt.quant_on_host;
+    c->q4_fused_rows = opt.q4_fused_rows;
+    c->graphs_on = opt.graph != 0;
+#ifdef VITX_LAB
+    if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);
+    if (const char *e = getenv("VITX_SPLIT")) c->split_first = atoi(e);
+#endif
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 
     const int D = c->D, tn = c->tn;
@@ -330,9 +324,8 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
     if ((rc = upload_f32(c.get(), T("head.bias"), &c->head_b, c->C_pad))) return rc;
     if ((rc = upload_weight(c.get(), T("head.weight"), c->C, D, c->C_pad, &c->head_w, &c->head_q))) return rc;
 
-    // sub-batch slices (VITX_STREAMS overrides; 1 = single stream).  Small contexts stay single-slice.
-    int ns = 2;
-    if (const char *e = getenv("VITX_STREAMS")) ns = atoi(e);
+    // sub-batch slices (vitx_ctx_options::streams; 1 = single stream).  Small contexts stay single-slice.
+    int ns = opt.streams > 0 ? opt.streams : 2;
     if (ns < 1) ns = 1;
     if (ns > 4) ns = 4;
     if (max_batch < 8 * ns) ns = 1;
@@ -349,7 +342,6 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
         if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
-        if ((rc = c->dmalloc((void **)&sl.ln_cnt, (Mpad / 256 + 1) * sizeof(int), true))) return rc;
         // expansion scratch for quantised matrices: one buffer per matrix kind, shared by all layers (the largest layer decides)
         for (int k = 0; k < W_PER_LAYER; ++k) {
             size_t need = 0;
@@ -365,7 +357,7 @@ int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, v
             // so odd slices take the high-priority pool and even slices the normal one: never the same queue.
             int least = 0, greatest = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            const int prio = (i & 1) && !getenv("VITX_FLAT_PRIORITY") ? greatest : 0;
+            const int prio = (i & 1) ? greatest : 0;
             HIP_TRY(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio));
             HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
@@ -433,7 +425,11 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         }
         return VITX_OK;
     };
-    bool ln1_done = false;                           // norm1 of the coming layer was produced by the previous layer's fc2 GEMM
+#ifdef VITX_LAB
+    const int skip = c->skip;
+#else
+    constexpr int skip = 0;
+#endif
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
         const void *Wl[W_PER_LAYER] = {w.qkv_w, w.proj_w, w.fc1_w, w.fc2_w};
@@ -448,33 +444,25 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             }
             if (any && (rc = expand(todo, sl.Wq, W_PER_LAYER))) return rc;
         }
-        if (!ln1_done) {   // norm1 (vit.cpp:808-812)
+        {   // norm1 (vit.cpp:808-812)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
-            if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
+            if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // qkv projection (vit.cpp:820-821)
         if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV]))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
-            if (!(c->skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
+            if (!(skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873)
-        // norm2 (vit.cpp:881-885) rides in the GEMM where it can: the workgroup that completes a 256-row block of X normalises it into U
-        // (U is also this GEMM's A operand -- a row block's rows are only overwritten after all of its column tiles have been read)
-        GemmArgs ln2{}; ln2.ln_out = sl.U; ln2.ln_cnt = sl.ln_cnt; ln2.ln_w = w.ln2_w; ln2.ln_b = w.ln2_b; ln2.ln_eps = c->hp.eps;
-        bool ln2_done = false;
-        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, Wl[W_PROJ], w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4, Fl[W_PROJ], &ln2, &ln2_done))) return rc;
-        if (!ln2_done) {   // norm2 (vit.cpp:881-885)
+        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, Wl[W_PROJ], w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4, Fl[W_PROJ]))) return rc;
+        {   // norm2 (vit.cpp:881-885)
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
-            if (!(c->skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
+            if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // MLP (vit.cpp:889-900)
         if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1]))) return rc;
-        // the NEXT layer's norm1 rides in fc2 the same way (the last layer is followed by the cls-row norm instead)
-        GemmArgs ln1{}; ln1_done = false;
-        if (il + 1 < c->L) { const LayerW &nx = c->layers[il + 1]; ln1.ln_out = sl.U; ln1.ln_cnt = sl.ln_cnt; ln1.ln_w = nx.ln1_w; ln1.ln_b = nx.ln1_b; ln1.ln_eps = c->hp.eps; }
-        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2],
-                       il + 1 < c->L ? &ln1 : nullptr, &ln1_done))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2]))) return rc;
         if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D.  ViTSTR (vitstr.cpp:864-895) keeps the first
@@ -519,16 +507,7 @@ static double gemm_round_cost(long rows, int N, int K, int n_cu) {
 static void split_batch(const vitx_ctx *c, int n, int ns, int *m) {
     const int base = n / ns, extra = n % ns;
     for (int i = 0; i < ns; ++i) m[i] = base + (i < extra ? 1 : 0);
-    if (c->split_override[0] > 0) {
-        int left = n, i = 0;
-        for (; i < ns - 1; ++i) {
-            const int v = c->split_override[i];
-            if (v <= 0 || v >= left) break;
-            m[i] = v; left -= v;
-        }
-        if (i == ns - 1) { m[ns - 1] = left; return; }
-        for (int k = 0; k < ns; ++k) m[k] = base + (k < extra ? 1 : 0);
-    }
+    if (c->split_first > 0 && ns == 2 && c->split_first < n) { m[0] = c->split_first; m[1] = n - c->split_first; return; }
     if (ns != 2) return;
     const int n_cu = c->tune->n_cu;
     const int D = c->D;
@@ -583,7 +562,7 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
     // while per-kernel profiling is on, sub-batches run back to back on the caller's stream so that every
     // event pair brackets one kernel running alone (exclusive durations, comparable with rocprofv3 --stats)
-    const bool serial = c->prof_on || c->slices_serial;
+    const bool serial = c->prof_on;
     const int ns = (c->nslices > 1 && n >= 8 * c->nslices) ? c->nslices : 1;
     if (ns == 1) {
         if (c->graphs_on && !c->prof_on && c->trace_ids.empty()) {
@@ -692,7 +671,7 @@ static int op_gemm_impl(int dtype, int epi, int kernel, const void *a, const voi
     if (!t0) { set_error("vitx_op_gemm: kernel bring-up failed"); return VITX_ERR_HIP; }
     Tuning t = *t0;
     if (kernel == 2) t.gemm_split = 1;
-    else if (kernel == 1 || kernel == 3) { t.gemm_cfg = 1; t.pp_flags = kernel == 3 ? 4096 : 0; }      // ping-pong kernel: four-phase / two-burst schedule
+    else if (kernel == 1) t.gemm_cfg = 1;                  // ping-pong persistent kernel
     else if (kernel != 0) t.gemm_cfg = kernel;
     // W (and bias) must hold n_pad rows; rows beyond N are never stored
     GemmArgs g{};
@@ -733,20 +712,19 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *a, const void *qs, const voi
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c) { return c ? c->weight_bytes : 0; }
 
 int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
-    if (!qkv || !out || n_img <= 0 || kernel < 0 || (kernel & 15) > 4) return VITX_ERR_ARG;
+    if (!qkv || !out || n_img <= 0 || kernel < 0) return VITX_ERR_ARG;
     const Tuning *t0 = tuning_for_device(-1);
     if (!t0) { set_error("vitx_op_attention: kernel bring-up failed"); return VITX_ERR_HIP; }
     Tuning t = *t0;
+#ifdef VITX_LAB
     t.attn_flags = kernel >> 4; kernel &= 15;                // bits 4+: ablation build of the pipelined kernel (tools/attn_bench.py only)
-    if (kernel == 4) {                                       // persistent single-pass kernel (193..224 tokens)
+#endif
+    if (kernel == ATTN_PERSIST) {                            // persistent single-pass kernel (193..224 tokens)
         if (N <= 192 || N > 224) { set_error("vitx_op_attention: the persistent kernel takes 193..224 tokens, not %d", N); return VITX_ERR_UNSUPPORTED; }
-        t.attn_waves = -3;
-    } else if (kernel == 3) t.attn_waves = -1;               // pipelined two-pass kernel
-    else if (kernel == 2) t.attn_waves = 0;                  // streaming kernel
-    else if (kernel == 1) {                                  // single-pass kernel, also where the automatic choice prefers the pipelined one
+    } else if (kernel == ATTN_SINGLE) {                      // single-pass kernel, also where the automatic choice prefers the pipelined one
         if (!attention_single_pass_supports(N)) { set_error("vitx_op_attention: no single-pass instantiation for %d tokens", N); return VITX_ERR_UNSUPPORTED; }
-        t.attn_waves = -2;
-    }
+    } else if (kernel != ATTN_AUTO && kernel != ATTN_FLOW) { set_error("vitx_op_attention: unknown kernel id %d", kernel); return VITX_ERR_ARG; }
+    t.attn_kernel = kernel;
     hipError_t e = launch_attention(t, dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_attention: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? VITX_ERR_UNSUPPORTED : VITX_ERR_HIP; }
     return VITX_OK;

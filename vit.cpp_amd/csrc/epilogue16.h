@@ -7,7 +7,7 @@
 // element is the same bits whichever kernel the batch size selects (tests/test_gpu_parity_r02.py).
 //
 // Epilogues (reference: /root/reference/vit.cpp): EPI_BIAS qkv (:820-823); EPI_BIAS_GELU fc1 + ggml_gelu through the fp16
-// table (:888-893; the value is rounded to the operand type before and after the activation); EPI_BIAS_RESID proj / fc2 +
+// table (:888-893; gelu_out_pair: F16 rounds the value before and after the activation as the table does, BF16 only after); EPI_BIAS_RESID proj / fc2 +
 // residual add in f32 (:868-873, :899-902); EPI_BIAS_F32 classifier head (:917-922); EPI_PATCH patch embedding + position
 // embedding, patch row -> token row (:774-800).
 #pragma once
@@ -41,11 +41,9 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][T
                 const int row = row0 + t * 16;
                 if (!FULL && row >= g.M_real) continue;
                 const f32x4 v = acc[t][u] + bv;
-                v2 p0 = round_pair<T>(v[0], v[1]), p1 = round_pair<T>(v[2], v[3]);
-                if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
-                    const f32x2 y0 = gelu_tanh2(f32x2{(float)p0[0], (float)p0[1]}), y1 = gelu_tanh2(f32x2{(float)p1[0], (float)p1[1]});
-                    p0 = round_pair<T>(y0[0], y0[1]); p1 = round_pair<T>(y1[0], y1[1]);
-                }
+                v2 p0, p1;
+                if constexpr (EPI == EPI_BIAS_GELU) { p0 = gelu_out_pair<T>(v[0], v[1]); p1 = gelu_out_pair<T>(v[2], v[3]); }
+                else { p0 = round_pair<T>(v[0], v[1]); p1 = round_pair<T>(v[2], v[3]); }
                 T *o = (T *)g.out + (size_t)row * g.ldo + c;
                 if (vec) *(v4 *)o = v4{p0[0], p0[1], p1[0], p1[1]};
                 else {
@@ -145,11 +143,9 @@ __device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const f32x4 v = acc[2 * i + tp][u] + bq[u];
-                    v2 p0 = round_pair<T>(v[0], v[1]), p1 = round_pair<T>(v[2], v[3]);
-                    if constexpr (EPI == EPI_BIAS_GELU) {      // round to the operand type (ggml's fp16 LUT input), tanh-GELU, round (LUT output)
-                        const f32x2 y0 = gelu_tanh2(f32x2{(float)p0[0], (float)p0[1]}), y1 = gelu_tanh2(f32x2{(float)p1[0], (float)p1[1]});
-                        p0 = round_pair<T>(y0[0], y0[1]); p1 = round_pair<T>(y1[0], y1[1]);
-                    }
+                    v2 p0, p1;
+                    if constexpr (EPI == EPI_BIAS_GELU) { p0 = gelu_out_pair<T>(v[0], v[1]); p1 = gelu_out_pair<T>(v[2], v[3]); }
+                    else { p0 = round_pair<T>(v[0], v[1]); p1 = round_pair<T>(v[2], v[3]); }
                     // columns u * 16 + 4 g4 .. + 3 -> bytes u * 32 + 8 g4 of the 128-byte patch row: 16-byte slot 2u + (g4 >> 1), half g4 & 1
                     *(u32x2 *)(patch + prow * 128 + (((2 * u + (g4 >> 1)) * 16) ^ x16) + (g4 & 1) * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
                 }

@@ -395,7 +395,9 @@ static hipError_t launch_ring_e(const GemmArgs &a, int cfg, int n_cu, hipStream_
 }
 template <typename T>
 static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, int n_cu, hipStream_t stream, bool prepare) {
+#ifdef VITX_LAB      // ablation build of the ring kernel (tools/): garbage results by design, never in the product library
     if (a.dbg) return epi == EPI_BIAS ? launch_ring_e<T, EPI_BIAS, true>(a, cfg, n_cu, stream, prepare) : hipErrorInvalidValue;
+#endif
     switch (epi) {
     case EPI_BIAS: return launch_ring_e<T, EPI_BIAS, false>(a, cfg, n_cu, stream, prepare);
     case EPI_BIAS_GELU: return launch_ring_e<T, EPI_BIAS_GELU, false>(a, cfg, n_cu, stream, prepare);
@@ -416,8 +418,10 @@ bool gemm_ring_supports(const GemmArgs &a, int cfg) {
 hipError_t launch_gemm_ring(const Tuning &t, int dtype, int epi, const GemmArgs &a0, int cfg, hipStream_t stream, bool prepare) {
     if (prepare) return dtype == DT_F16 ? launch_ring_t<_Float16>(a0, epi, cfg, t.n_cu, stream, true) : launch_ring_t<__bf16>(a0, epi, cfg, t.n_cu, stream, true);
     if (!gemm_ring_supports(a0, cfg)) return hipErrorInvalidValue;
+    GemmArgs a = a0; a.dbg = 0;
+#ifdef VITX_LAB
     const int dbg = t.gemm_dbg;
-    GemmArgs a = a0; a.dbg = dbg;
+    a.dbg = dbg;
     if (dbg & 32) {      // experiment mode: collect and print a per-block timeline (synchronous)
         RingCfg c; parse_cfg(cfg, c);
         const int nwg = (a.M / (c.nwm * c.wmt * 32)) * (a.N_pad / (c.nwn * c.wnt * 32));
@@ -432,6 +436,7 @@ hipError_t launch_gemm_ring(const Tuning &t, int dtype, int epi, const GemmArgs 
         (void)hipHostFree(buf);
         return e;
     }
+#endif
     return dtype == DT_F16 ? launch_ring_t<_Float16>(a, epi, cfg, t.n_cu, stream, false) : launch_ring_t<__bf16>(a, epi, cfg, t.n_cu, stream, false);
 }
 

@@ -2,9 +2,10 @@
 //
 // The reference calls stbi_load(fname, &nx, &ny, &nc, 3) from stb_image.h, which lives in the absent ggml submodule
 // (vit.h:5 includes "ggml/examples/stb_image.h"), so the decoder is written here from the file-format specifications:
-//   * JPEG (ITU T.81): baseline / extended-sequential and PROGRESSIVE Huffman, 8-bit, 1 or 3 components, sampling factors 1-2,
-//     restart intervals -- three of the reference's ten bundled images are progressive;
-//   * PNG (RFC 2083) with its own zlib inflate: non-interlaced, colour types 0/2/3/4/6, bit depths 1-16, alpha dropped;
+//   * JPEG (ITU T.81): baseline / extended-sequential and PROGRESSIVE Huffman, 8-bit, 1, 3 or 4 components (YCbCr, Adobe RGB, CMYK and
+//     YCCK through the APP14 colour-transform flag, as stbi_load(..., 3) converts them), sampling factors 1-2, restart intervals --
+//     three of the reference's ten bundled images are progressive;
+//   * PNG (RFC 2083) with its own zlib inflate: plain and Adam7-interlaced, colour types 0/2/3/4/6, bit depths 1-16, alpha dropped;
 //   * binary PPM (P6), kept for the C++ example.
 // Output is what stbi_load(..., 3) returns: tightly packed RGB u8, top row first.
 // Where the standard leaves arithmetic to the decoder (IDCT, chroma upsampling, YCbCr -> RGB) the choices follow stb_image's
@@ -88,7 +89,8 @@ struct Jpeg {
     bool progressive = false;
     uint16_t qt[4][64]; bool qt_present[4] = {false, false, false, false};
     Huff hdc[4], hac[4];
-    Component comp[3];
+    Component comp[4];
+    int app14_transform = -1; bool jfif = false;      // Adobe APP14 colour transform (0 RGB/CMYK, 1 YCbCr, 2 YCCK; -1 = no marker), JFIF APP0 seen
     int restart_interval = 0;
     // bit reader
     uint32_t bitbuf = 0; int bitcnt = 0; int marker = -1; bool no_more = false;
@@ -224,9 +226,12 @@ struct Jpeg {
         if (u8() != 8) fail("jpeg: only 8-bit samples are supported");
         height = u16(); width = u16(); ncomp = u8();
         if (width <= 0 || height <= 0) fail("jpeg: zero-sized image");
-        if (ncomp != 1 && ncomp != 3) fail("jpeg: only 1- and 3-component images are supported");
+        if (ncomp != 1 && ncomp != 3 && ncomp != 4) fail("jpeg: only 1-, 3- and 4-component images are supported");
         if (len != 8 + 3 * ncomp) fail("jpeg: bad SOF length");
+        // the coefficient buffers are allocated from these two numbers before any scan data has been seen: refuse sizes no JPEG of this
+        // many bytes can encode (a block costs at least a few bits; 1024 pixels per file byte is far beyond any real stream)
         if ((int64_t)width * height > (int64_t)1 << 28) fail("jpeg: image too large");
+        if ((int64_t)width * height > (int64_t)1 << 24 && (int64_t)width * height > (int64_t)(end - p) * 1024) fail("jpeg: image size implausible for the file size");
         for (int i = 0; i < ncomp; ++i) {
             Component &c = comp[i];
             c.id = u8(); const int hv = u8(); c.h = hv >> 4; c.v = hv & 15; c.tq = u8();
@@ -272,7 +277,7 @@ struct Jpeg {
         const int len = u16();
         const int ns = u8();
         if (ns < 1 || ns > ncomp || len != 6 + 2 * ns) fail("jpeg: bad SOS");
-        int order[3];
+        int order[4];
         for (int i = 0; i < ns; ++i) {
             const int id = u8(), tt = u8();
             int k = -1;
@@ -327,13 +332,15 @@ struct Jpeg {
 
     // stb_image's integer IDCT (jidctint "islow" with 12-bit constants), output clamped to u8 with the +128 level shift folded in
     static void idct(const int16_t *in, const uint16_t *q, uint8_t *out, int stride) {
-        int val[64];
+        // 64-bit intermediates: identical results on every valid stream; corrupt coefficients (int16 x 16-bit DQT entry x 4096)
+        // cannot overflow (r02 advisor: signed overflow is undefined behaviour)
+        int64_t val[64];
         auto f2f = [](double x) { return (int)(x * 4096 + 0.5); };
         static const int c0541 = f2f(0.5411961), c1847 = f2f(-1.847759065), c0765 = f2f(0.765366865), c1175 = f2f(1.175875602), c0298 = f2f(0.298631336),
                          c2053 = f2f(2.053119869), c3072 = f2f(3.072711026), c1501 = f2f(1.501321110), c0899 = f2f(-0.899976223), c2562 = f2f(-2.562915447),
                          c1961 = f2f(-1.961570560), c0390 = f2f(-0.390180644);
 #define VITX_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                                          \
-        int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                                   \
+        int64_t t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                               \
         p2 = s2; p3 = s6; p1 = (p2 + p3) * c0541; t2 = p1 + p3 * c1847; t3 = p1 + p2 * c0765;                                     \
         p2 = s0; p3 = s4; t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;                                                           \
         x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                                                                   \
@@ -342,22 +349,22 @@ struct Jpeg {
         p1 = p5 + p1 * c0899; p2 = p5 + p2 * c2562; p3 = p3 * c1961; p4 = p4 * c0390;                                             \
         t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
         for (int i = 0; i < 8; ++i) {
-            const int16_t *d = in + i; const uint16_t *dq = q + i; int *v = val + i;
+            const int16_t *d = in + i; const uint16_t *dq = q + i; int64_t *v = val + i;
             if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0) {
-                const int dc = d[0] * dq[0] * 4;
+                const int64_t dc = (int64_t)d[0] * dq[0] * 4;
                 v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
             } else {
-                VITX_IDCT_1D(d[0] * dq[0], d[8] * dq[8], d[16] * dq[16], d[24] * dq[24], d[32] * dq[32], d[40] * dq[40], d[48] * dq[48], d[56] * dq[56])
+                VITX_IDCT_1D((int64_t)d[0] * dq[0], (int64_t)d[8] * dq[8], (int64_t)d[16] * dq[16], (int64_t)d[24] * dq[24], (int64_t)d[32] * dq[32], (int64_t)d[40] * dq[40], (int64_t)d[48] * dq[48], (int64_t)d[56] * dq[56])
                 x0 += 512; x1 += 512; x2 += 512; x3 += 512;
                 v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
                 v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
             }
         }
-        auto clamp = [](int x) { return (uint8_t)((unsigned)x > 255 ? (x < 0 ? 0 : 255) : x); };
+        auto clamp = [](int64_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); };
         for (int i = 0; i < 8; ++i) {
-            const int *v = val + i * 8; uint8_t *o = out + i * stride;
+            const int64_t *v = val + i * 8; uint8_t *o = out + i * stride;
             VITX_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-            x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
+            x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);      // fits: |x| < 2^40
             o[0] = clamp((x0 + t3) >> 17); o[7] = clamp((x0 - t3) >> 17); o[1] = clamp((x1 + t2) >> 17); o[6] = clamp((x1 - t2) >> 17);
             o[2] = clamp((x2 + t1) >> 17); o[5] = clamp((x2 - t1) >> 17); o[3] = clamp((x3 + t0) >> 17); o[4] = clamp((x3 - t0) >> 17);
         }
@@ -405,7 +412,12 @@ struct Jpeg {
             case 0x00: break;
             default:
                 if (m >= 0xD0 && m <= 0xD7) break;               // stray restart marker
-                { const int len = u16(); if (len < 2 || p + len - 2 > end) fail("jpeg: truncated segment"); p += len - 2; }
+                {
+                    const int len = u16(); if (len < 2 || p + len - 2 > end) fail("jpeg: truncated segment");
+                    if (m == 0xE0 && len >= 7 && !memcmp(p, "JFIF", 5)) jfif = true;
+                    if (m == 0xEE && len >= 14 && !memcmp(p, "Adobe", 5)) app14_transform = p[11];       // version(2) flags0(2) flags1(2) transform(1)
+                    p += len - 2;
+                }
             }
             if (p >= end) done = true;
         }
@@ -424,8 +436,8 @@ struct Jpeg {
                 for (int x = 0; x < width; ++x) { const uint8_t g = comp[0].pix[(size_t)y * comp[0].pw + x]; uint8_t *o = &rgb[((size_t)y * width + x) * 3]; o[0] = o[1] = o[2] = g; }
             return rgb;
         }
-        struct Res { void (*fn)(uint8_t *, const uint8_t *, const uint8_t *, int); int hs, vs, ystep, ypos, w_lores; const uint8_t *line0, *line1; std::vector<uint8_t> buf; } r[3];
-        for (int k = 0; k < 3; ++k) {
+        struct Res { void (*fn)(uint8_t *, const uint8_t *, const uint8_t *, int); int hs, vs, ystep, ypos, w_lores; const uint8_t *line0, *line1; std::vector<uint8_t> buf; } r[4];
+        for (int k = 0; k < ncomp; ++k) {
             Component &c = comp[k];
             r[k].hs = hmax / c.h; r[k].vs = vmax / c.v; r[k].ystep = r[k].vs >> 1; r[k].ypos = 0;
             r[k].w_lores = (width + r[k].hs - 1) / r[k].hs;
@@ -436,9 +448,15 @@ struct Jpeg {
         auto f2f = [](float x) { return ((int)(x * 4096.0f + 0.5f)) << 8; };
         const int cr_r = f2f(1.40200f), cr_g = -f2f(0.71414f), cb_g = -f2f(0.34414f), cb_b = f2f(1.77200f);
         auto clamp = [](int x) { return (uint8_t)((unsigned)x > 255 ? (x < 0 ? 0 : 255) : x); };
-        const uint8_t *row[3];
+        auto blinn = [](int x, int y) { const unsigned t = (unsigned)(x * y + 128); return (uint8_t)((t + (t >> 8)) >> 8); };     // x * y / 255, rounded
+        // what stbi_load(..., 3) does with the components: three components are RGB when they are named 'R','G','B' or an Adobe marker
+        // says "no transform" (and no JFIF marker contradicts it), otherwise YCbCr; four are CMYK (transform 0), YCCK (2) or YCbCr + an
+        // ignored fourth; Adobe writes CMYK inverted, hence the products with k
+        const bool named_rgb = ncomp == 3 && comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B';
+        const bool is_rgb = ncomp == 3 && (named_rgb || (app14_transform == 0 && !jfif));
+        const uint8_t *row[4];
         for (int j = 0; j < height; ++j) {
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < ncomp; ++k) {
                 Res &q = r[k];
                 const bool y_bot = q.ystep >= (q.vs >> 1);
                 if (q.fn == up_1) row[k] = y_bot ? q.line1 : q.line0;
@@ -451,9 +469,19 @@ struct Jpeg {
             }
             uint8_t *o = &rgb[(size_t)j * width * 3];
             for (int i = 0; i < width; ++i) {
+                if (is_rgb) { o[i * 3] = row[0][i]; o[i * 3 + 1] = row[1][i]; o[i * 3 + 2] = row[2][i]; continue; }
+                if (ncomp == 4 && app14_transform == 0) {       // CMYK
+                    const int k = row[3][i];
+                    o[i * 3] = blinn(row[0][i], k); o[i * 3 + 1] = blinn(row[1][i], k); o[i * 3 + 2] = blinn(row[2][i], k);
+                    continue;
+                }
                 const int yf = (row[0][i] << 20) + (1 << 19), cb = row[1][i] - 128, cr = row[2][i] - 128;
                 int rr = yf + cr * cr_r, gg = yf + cr * cr_g + ((cb * cb_g) & 0xffff0000), bb = yf + cb * cb_b;
                 o[i * 3] = clamp(rr >> 20); o[i * 3 + 1] = clamp(gg >> 20); o[i * 3 + 2] = clamp(bb >> 20);
+                if (ncomp == 4 && app14_transform == 2) {       // YCCK
+                    const int k = row[3][i];
+                    o[i * 3] = blinn(255 - o[i * 3], k); o[i * 3 + 1] = blinn(255 - o[i * 3 + 1], k); o[i * 3 + 2] = blinn(255 - o[i * 3 + 2], k);
+                }
             }
         }
         return rgb;
@@ -466,6 +494,8 @@ struct Jpeg {
 struct Inflate {
     const uint8_t *p, *end; uint32_t bits = 0; int nbits = 0;
     std::vector<uint8_t> out;
+    size_t limit = (size_t)-1;      // the caller knows how many bytes a valid stream expands to: anything beyond is a decompression bomb
+    void grown() { if (out.size() > limit) fail("png: the zlib stream expands beyond the image size"); }
     struct Tab { uint16_t count[16]; uint16_t sym[288]; };
     int bit() { if (!nbits) { if (p >= end) fail("png: truncated zlib stream"); bits = *p++; nbits = 8; } const int b = bits & 1; bits >>= 1; --nbits; return b; }
     int get(int n) { int v = 0; for (int i = 0; i < n; ++i) v |= bit() << i; return v; }
@@ -494,7 +524,7 @@ struct Inflate {
         static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
         for (;;) {
             int s = sym(lit);
-            if (s < 256) { out.push_back((uint8_t)s); continue; }
+            if (s < 256) { out.push_back((uint8_t)s); grown(); continue; }
             if (s == 256) return;
             s -= 257;
             if (s >= 29) fail("png: bad length code");
@@ -505,6 +535,7 @@ struct Inflate {
             if (d > out.size()) fail("png: distance beyond the window");
             const size_t from = out.size() - d;
             for (int i = 0; i < len; ++i) out.push_back(out[from + i]);
+            grown();
         }
     }
     void run() {
@@ -520,7 +551,7 @@ struct Inflate {
                 if (end - p < 4) fail("png: truncated stored block");
                 const int len = p[0] | (p[1] << 8), nlen = p[2] | (p[3] << 8); p += 4;
                 if ((len ^ 0xffff) != nlen || end - p < len) fail("png: bad stored block");
-                out.insert(out.end(), p, p + len); p += len;
+                out.insert(out.end(), p, p + len); p += len; grown();
             } else if (type == 1) {
                 uint8_t l[288]; for (int i = 0; i < 144; ++i) l[i] = 8; for (int i = 144; i < 256; ++i) l[i] = 9; for (int i = 256; i < 280; ++i) l[i] = 7; for (int i = 280; i < 288; ++i) l[i] = 8;
                 uint8_t d[30]; for (int i = 0; i < 30; ++i) d[i] = 5;
@@ -577,45 +608,69 @@ std::vector<uint8_t> decode_png(const uint8_t *data, size_t n, int &w, int &h) {
         p += 12 + len;
     }
     if (ctype < 0) fail("png: no IHDR");
-    if (interlace) fail("png: interlaced files are not supported");
+    if (interlace > 1) fail("png: unknown interlace method");
     int channels = 0;
     switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break; case 4: channels = 2; break; case 6: channels = 4; break; default: fail("png: bad colour type"); }
     if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4)))) fail("png: unsupported bit depth");
     if (ctype == 3 && (depth == 16 || plte.size() < 3)) fail("png: bad palette image");
-    Inflate z; z.p = idat.data(); z.end = idat.data() + idat.size(); z.out.reserve((size_t)h * ((size_t)w * channels * depth / 8 + 2));
+    const size_t bpp = (size_t)(channels * depth + 7) / 8;
+    auto row_bytes = [&](int pw) { return ((size_t)pw * channels * depth + 7) / 8; };
+    // Adam7 (RFC 2083 section 2.6): seven reduced images, each filtered on its own; pass p holds pixels (xo + i * xs, yo + j * ys)
+    static const int xo[7] = {0, 4, 0, 2, 0, 1, 0}, yo[7] = {0, 0, 4, 0, 2, 0, 1}, xs[7] = {8, 8, 4, 4, 2, 2, 1}, ys[7] = {8, 8, 8, 4, 4, 2, 2};
+    size_t need = 0;
+    if (!interlace) need = (row_bytes(w) + 1) * (size_t)h;
+    else for (int ps = 0; ps < 7; ++ps) { const int pw = (w - xo[ps] + xs[ps] - 1) / xs[ps], ph = (h - yo[ps] + ys[ps] - 1) / ys[ps]; if (pw > 0 && ph > 0) need += (row_bytes(pw) + 1) * (size_t)ph; }
+    Inflate z; z.p = idat.data(); z.end = idat.data() + idat.size();
+    z.limit = need;                                                   // a valid stream expands to exactly `need` bytes
+    z.out.reserve(need < ((size_t)64 << 20) ? need : ((size_t)64 << 20));
     z.run();
-    const size_t bpp = (size_t)(channels * depth + 7) / 8, stride = ((size_t)w * channels * depth + 7) / 8;
-    if (z.out.size() < (stride + 1) * (size_t)h) fail("png: not enough image data");
-    std::vector<uint8_t> cur(stride), prev(stride, 0), rgb((size_t)w * h * 3);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t *src = &z.out[(size_t)y * (stride + 1)];
-        const int ft = src[0]; ++src;
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int v;
-            switch (ft) {
-            case 0: v = src[i]; break;
-            case 1: v = src[i] + a; break;
-            case 2: v = src[i] + b; break;
-            case 3: v = src[i] + ((a + b) >> 1); break;
-            case 4: { const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c); v = src[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); break; }
-            default: fail("png: bad filter type");
+    if (z.out.size() < need) fail("png: not enough image data");
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    // un-filter a pw x ph (reduced) image starting at src and hand every pixel to put(x, y, r, g, b)
+    auto unfilter = [&](const uint8_t *src, int pw, int ph, auto &&put) {
+        const size_t stride = row_bytes(pw);
+        std::vector<uint8_t> cur(stride), prev(stride, 0);
+        for (int y = 0; y < ph; ++y) {
+            const int ft = src[0]; ++src;
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int v;
+                switch (ft) {
+                case 0: v = src[i]; break;
+                case 1: v = src[i] + a; break;
+                case 2: v = src[i] + b; break;
+                case 3: v = src[i] + ((a + b) >> 1); break;
+                case 4: { const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c); v = src[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); break; }
+                default: fail("png: bad filter type");
+                }
+                cur[i] = (uint8_t)v;
             }
-            cur[i] = (uint8_t)v;
+            src += stride;
+            for (int x = 0; x < pw; ++x) {
+                auto sample = [&](int ch) -> int {      // channel ch of pixel x scaled to 8 bits
+                    if (depth == 8) return cur[(size_t)x * channels + ch];
+                    if (depth == 16) return cur[((size_t)x * channels + ch) * 2];
+                    const int per = 8 / depth, v = (cur[x / per] >> ((per - 1 - x % per) * depth)) & ((1 << depth) - 1);
+                    return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
+                };
+                if (ctype == 3) { const size_t i = (size_t)sample(0) * 3; if (i + 3 > plte.size()) fail("png: palette index out of range"); put(x, y, plte[i], plte[i + 1], plte[i + 2]); }
+                else if (ctype == 0 || ctype == 4) { const uint8_t g = (uint8_t)sample(0); put(x, y, g, g, g); }
+                else put(x, y, (uint8_t)sample(0), (uint8_t)sample(1), (uint8_t)sample(2));
+            }
+            prev.swap(cur);
         }
-        uint8_t *o = &rgb[(size_t)y * w * 3];
-        for (int x = 0; x < w; ++x) {
-            auto sample = [&](int ch) -> int {      // channel ch of pixel x scaled to 8 bits
-                if (depth == 8) return cur[(size_t)x * channels + ch];
-                if (depth == 16) return cur[((size_t)x * channels + ch) * 2];
-                const int per = 8 / depth, v = (cur[x / per] >> ((per - 1 - x % per) * depth)) & ((1 << depth) - 1);
-                return ctype == 3 ? v : v * 255 / ((1 << depth) - 1);
-            };
-            if (ctype == 3) { const size_t i = (size_t)sample(0) * 3; if (i + 3 > plte.size()) fail("png: palette index out of range"); o[x * 3] = plte[i]; o[x * 3 + 1] = plte[i + 1]; o[x * 3 + 2] = plte[i + 2]; }
-            else if (ctype == 0 || ctype == 4) { const uint8_t g = (uint8_t)sample(0); o[x * 3] = o[x * 3 + 1] = o[x * 3 + 2] = g; }
-            else { o[x * 3] = (uint8_t)sample(0); o[x * 3 + 1] = (uint8_t)sample(1); o[x * 3 + 2] = (uint8_t)sample(2); }
+        return src;
+    };
+    if (!interlace) {
+        unfilter(z.out.data(), w, h, [&](int x, int y, uint8_t r, uint8_t g, uint8_t b) { uint8_t *o = &rgb[((size_t)y * w + x) * 3]; o[0] = r; o[1] = g; o[2] = b; });
+    } else {
+        const uint8_t *src = z.out.data();
+        for (int ps = 0; ps < 7; ++ps) {
+            const int pw = (w - xo[ps] + xs[ps] - 1) / xs[ps], ph = (h - yo[ps] + ys[ps] - 1) / ys[ps];
+            if (pw <= 0 || ph <= 0) continue;
+            src = unfilter(src, pw, ph, [&](int x, int y, uint8_t r, uint8_t g, uint8_t b) {
+                uint8_t *o = &rgb[((size_t)(yo[ps] + y * ys[ps]) * w + (xo[ps] + x * xs[ps])) * 3]; o[0] = r; o[1] = g; o[2] = b; });
         }
-        prev.swap(cur);
     }
     return rgb;
 }
@@ -629,7 +684,10 @@ std::vector<uint8_t> decode_ppm(const uint8_t *data, size_t n, int &w, int &h) {
         int v = 0; while (pos < n && data[pos] >= '0' && data[pos] <= '9') { v = v * 10 + (data[pos] - '0'); if (v > (1 << 28)) fail("ppm: bad header"); ++pos; }
         vals[got++] = v;
     }
-    ++pos;      // the single whitespace byte after maxval
+    // exactly one whitespace byte separates maxval from the raster; a file that ends with the header has none (r02 advisor finding:
+    // the unconditional ++pos moved past the end and the unsigned `n - pos` below wrapped around)
+    if (pos >= n || !(data[pos] == ' ' || data[pos] == '\n' || data[pos] == '\r' || data[pos] == '\t')) fail("ppm: truncated (no raster after the header)");
+    ++pos;
     w = vals[0]; h = vals[1];
     if (w <= 0 || h <= 0 || vals[2] != 255 || (int64_t)w * h > (int64_t)1 << 28) fail("ppm: only 8-bit P6 files are supported");
     if (n - pos < (size_t)w * h * 3) fail("ppm: truncated");

@@ -26,15 +26,11 @@ struct GemmArgs {
     int K;        // multiple of 64
     int lda, ldw, ldo;
     int tpi;      // EPI_PATCH: patch tokens per image (g*g)
-    int dbg;      // ablation bits for kernel experiments (VITX_GEMM_DBG): 1 no DMA in loop, 2 no ds_read in loop, 4 no MFMA, 8 no epilogue
+    int dbg;      // ablation bits of the ring kernel's laboratory build (VITX_LAB only; 0 in the product)
     // q4_0 weights kept in block form (launch_gemm_q4 only): W = nibble plane [N_pad][K/2] bytes (16 per block), Wscale = f16 block
     // scales [N_pad][K/32]; both planes are the file's block_q4_0 fields re-laid out, 4.5 bits per weight
     const uint16_t *Wscale;
-    int group_m;  // ping-pong kernel: m-tiles per raster group (0 = the default, 8); VITX_GROUP_M / LAB_GROUP_M experiments
-    // EPI_BIAS_RESID on the ping-pong kernel with N == ldo (whole rows): when ln_out is set, the workgroup that finishes the LAST
-    // column tile of a 256-row block also normalises those rows (LayerNorm, vit.cpp:808-812 / 881-885) into ln_out [M][N] of the
-    // operand type.  ln_cnt: one zeroed int per row block (the last arriver resets it).
-    void *ln_out; int *ln_cnt; const float *ln_w, *ln_b; float ln_eps;
+    int group_m;  // ping-pong kernel: m-tiles per raster group (0 = the default, 8)
 };
 
 // ---- block-quantised weights resident in HBM (quant.hip) -------------------------------------------
@@ -50,36 +46,30 @@ hipError_t launch_dequant(int dtype, int qtype, const DequantJob *jobs, int njob
 hipError_t launch_gemm_q4(int dtype, int epi, const GemmArgs &a, hipStream_t stream);
 bool gemm_q4_supports(const GemmArgs &a);
 
-// Per-device launch parameters.  Everything a launcher used to keep in function-local statics (CU count, "dynamic LDS
-// attribute already set", getenv results) lives here: one immutable copy per device, built by tuning_for_device() under a
-// lock, so contexts on several GPUs (or host threads) of one process never share launch state.
+// Per-device launch parameters: one immutable copy per device, built by tuning_for_device() under a lock, so contexts on several GPUs
+// (or host threads) of one process never share launch state.  The product library reads NO environment variable here: the family
+// overrides below are explicit parameters of vitx_op_gemm_ex / vitx_op_attention_ex (parity tests); only the laboratory build
+// (-DVITX_LAB, tools/) maps VITX_* variables onto them.
+enum { ATTN_AUTO = 0, ATTN_SINGLE = 1, ATTN_FLOW = 3, ATTN_PERSIST = 4 };
 struct Tuning {
     int device = 0;
     int n_cu = 256;          // compute units of THIS device
-    int gemm_cfg = -1;       // VITX_GEMM_CFG: -1 auto, 0 = "v1" 128x128 kernel, 1 = "pp" forced, else a ring cfg (445, 945, 245, 122)
-    int gemm_pp = 1;         // VITX_GEMM_PP=0: wide tiles through the r01 ring/stream kernels instead of the ping-pong kernel
-    int gemm_stream = 1;     // VITX_GEMM_STREAM=0: one workgroup per tile (445) instead of the persistent 945 when the ring kernels run
-    int gemm_skinny = 1;     // VITX_GEMM_NOSKINNY unsets
-    int skinny_tiles = 128;  // VITX_SKINNY_TILES: 64x128 tiles (cfg 122) when fewer than this many 128x256 tiles exist (r02f: 64 -> 128, batches of 4-16 images)
-    int gemm_split = 0;      // VITX_GEMM_SPLIT=1: tail rows of a partial round re-tiled 128x256 in a second launch (r01 default; off since the persistent kernel)
-    int pp_flags = 0;        // VITX_PP_SCHED=2: the two-burst schedule of the ping-pong kernel (gemm_pp.hip FLAGS 4096) instead of the four-phase one
-    int pp_dbg = 0;          // VITX_PP_DBG: ablation bits of the ping-pong kernel's fused LayerNorm (64 no row pass, 128 no hand-off at all)
-    int ln_fuse = 1;         // VITX_LN_FUSE=0: LayerNorm always as its own kernel (never fused into the proj / fc2 GEMMs)
-    int group_m = 0;         // VITX_GROUP_M: raster group height of the ping-pong kernel (0 = its default)
-    int gemm_balance = 1;    // VITX_GEMM_BALANCE=0: launch one workgroup per CU even when the last round of tiles is partial
-    int gemm_dbg = 0;        // VITX_GEMM_DBG ablation bits of the ring kernel
-    int attn_flags = 0;      // ablation build of the pipelined attention kernel (tools/attn_bench.py); 0 = product
-    int attn_persist = 1;    // VITX_ATTN_PERSIST=0: never the persistent single-pass kernel (193..224 tokens)
-    int attn_waves = 4;      // VITX_ATTN_WAVES (-3: force the persistent kernel where it applies)
+    int gemm_cfg = -1;       // -1 automatic, 1 = the ping-pong kernel forced, else a ring configuration (445, 945, 245, 122)
+    int skinny_tiles = 128;  // 64x128 tiles (cfg 122) when fewer than this many 128x256 tiles exist (r02f: 64 -> 128, batches of 4-16 images)
+    int gemm_split = 0;      // 1: tail rows of a partial round re-tiled 128x256 in a second launch
+    int gemm_balance = 1;    // 0: one workgroup per CU even when the last round of tiles is partial
+    int group_m = 0;         // raster group height of the ping-pong kernel (0 = its default)
+    int ln_fuse = 1;         // 0: LayerNorm always as its own kernel (never fused into the proj / fc2 GEMMs)
+    int pp_flags = 0;        // ablation build of the ping-pong kernel (exists under VITX_LAB only)
+    int gemm_dbg = 0;        // ablation bits of the ring kernel (honoured under VITX_LAB only)
+    int attn_kernel = ATTN_AUTO;
+    int attn_flags = 0;      // ablation build of the pipelined attention kernel (exists under VITX_LAB only)
 };
-// Looks the device up (hipGetDevice when device < 0), reads the environment once per process, and on first use of a device
+// Looks the device up (hipGetDevice when device < 0) and on first use of a device
 // sets the dynamic-LDS attribute of every kernel instantiation on it.  Thread-safe.  Returns nullptr if HIP fails.
 const Tuning *tuning_for_device(int device);
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream);
-// true when launch_gemm would run this EPI_BIAS_RESID GEMM on the ping-pong kernel in one launch, so that the LayerNorm of its output
-// rows can be fused into it (GemmArgs::ln_out); the caller then skips the stand-alone layernorm launch
-bool gemm_can_fuse_layernorm(const Tuning &t, const GemmArgs &a);
 int gemm_tile_m();   // M granularity the GEMM needs (buffer row padding)
 int gemm_tile_n();
 

@@ -168,12 +168,12 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream, 
     return hipGetLastError();
 }
 
-// Kernel selection (t.gemm_cfg overrides it for experiments).
+// Kernel selection (t.gemm_cfg: an explicit family, set by vitx_op_gemm_ex for the parity tests).
 //   * >= 128 tiles of 256x256 and K % 128 == 0: the ping-pong persistent kernel (gemm_pp.hip);
 //   * otherwise 128x256 ring tiles, or the skinny 64x128 ring kernel when those would leave half of the CUs idle
 //     (a handful of images: same K order per element, so results stay bit-identical across batch sizes);
 //   * anything the ring kernels cannot tile: the v1 128x128 kernel.
-static int wide_ring_cfg(const Tuning &t, const GemmArgs &a) { return (t.gemm_stream && gemm_ring_supports(a, 945)) ? 945 : 445; }
+static int wide_ring_cfg(const GemmArgs &a) { return gemm_ring_supports(a, 945) ? 945 : 445; }
 
 // Persistent grid of the ping-pong kernel.  Tiles are dealt round-robin, so with one workgroup per CU a partial last round
 // (e.g. 339 tiles = 256 + 83) leaves most of the chip idle while the first round ran at the power-capped clock.  Balanced:
@@ -190,58 +190,48 @@ static int pp_grid(const Tuning &t, const GemmArgs &a) {
     return (int)(g < cap ? g : cap);
 }
 
-static bool is_wide(const Tuning &t, const GemmArgs &a) {
+static bool is_wide(const GemmArgs &a) {
     const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
     return a.M % 256 == 0 && a.N_pad % 256 == 0 && t256 >= 128 && (gemm_pp_supports(a) || gemm_ring_supports(a, 445));
 }
-bool gemm_can_fuse_layernorm(const Tuning &t, const GemmArgs &a) {
-    return t.ln_fuse && t.gemm_cfg < 0 && t.gemm_pp && !t.gemm_split && !t.pp_flags && a.M > 0 && is_wide(t, a) && gemm_pp_supports(a) &&
-           a.N == a.ldo && a.N == a.N_pad && a.N % 256 == 0 && a.N <= 1536;
-}
 static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a0, hipStream_t stream) {
-    GemmArgs a = a0; a.group_m = t.group_m; a.dbg = t.pp_dbg;
-    if (a.ln_out) return (epi == EPI_BIAS_RESID && gemm_can_fuse_layernorm(t, a)) ? launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, 32768) : hipErrorInvalidValue;
-    if (t.gemm_pp && gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
-    return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(t, a), stream);
+    GemmArgs a = a0; a.group_m = t.group_m;
+    if (gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
+    return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(a), stream);
 }
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
-    if (a.ln_out && !gemm_can_fuse_layernorm(t, a)) return hipErrorInvalidValue;      // the caller asks gemm_can_fuse_layernorm first
     int cfg = t.gemm_cfg;
     if (cfg == 1) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     if (cfg > 1) return gemm_ring_supports(a, cfg) ? launch_gemm_ring(t, dtype, epi, a, cfg, stream) : hipErrorInvalidValue;
-    if (cfg < 0) {
-        const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
-        const bool wide = a.M % 256 == 0 && a.N_pad % 256 == 0 && t256 >= 128 && (gemm_pp_supports(a) || gemm_ring_supports(a, 445));
-        if (wide) {
-            // Tail split: one 256x256 tile per CU per round means e.g. 591 tiles (N = 768) cost 3 rounds for 2.31 rounds of
-            // work.  Rows that fill whole rounds keep 256x256 tiles; the remaining rows are re-tiled 128x256 (half-cost tiles)
-            // in a second launch, which turns a 0.3-round remainder into ~0.35 rounds instead of a full one.
-            const int ntm = a.M / 256, ntn = a.N_pad / 256;
-            const long tiles = (long)ntm * ntn, rounds = tiles / t.n_cu, rem = tiles % t.n_cu;
-            if (t.gemm_split && epi != EPI_PATCH && rounds >= 1 && rem > 0 && rem <= t.n_cu * 6 / 10) {
-                const int m_main = (int)((rounds * t.n_cu) / ntn);                 // m-tiles that fit in whole rounds
-                const int rows_main = m_main * 256;
-                GemmArgs head = a, tail = a;
-                head.M = rows_main; head.M_real = std::min(a.M_real, rows_main);
-                const size_t esz_out = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? 2 : 4;
-                tail.A = (const char *)a.A + (size_t)rows_main * a.lda * 2;
-                tail.out = (char *)a.out + (size_t)rows_main * a.ldo * esz_out;
-                tail.M = a.M - rows_main; tail.M_real = a.M_real - rows_main;
-                if (m_main >= 1 && rows_main < a.M && gemm_ring_supports(tail, 245)) {
-                    hipError_t e = launch_wide(t, dtype, epi, head, stream);
-                    if (e != hipSuccess) return e;
-                    if (tail.M_real <= 0) return hipSuccess;
-                    return launch_gemm_ring(t, dtype, epi, tail, 245, stream);
-                }
+    if (is_wide(a)) {
+        // Tail split (t.gemm_split; off: with the persistent kernel the second launch costs 5 % of the step, profiles/r02_forward_sweeps.txt,
+        // re-measured with the 16x16x32 kernels in r02f): rows that fill whole rounds keep 256x256 tiles, the remaining rows are re-tiled
+        // 128x256 (half-cost tiles) in a second launch.  Kept reachable through vitx_op_gemm_ex(kernel 2) so the path stays tested.
+        const int ntm = a.M / 256, ntn = a.N_pad / 256;
+        const long tiles = (long)ntm * ntn, rounds = tiles / t.n_cu, rem = tiles % t.n_cu;
+        if (t.gemm_split && epi != EPI_PATCH && rounds >= 1 && rem > 0 && rem <= t.n_cu * 6 / 10) {
+            const int m_main = (int)((rounds * t.n_cu) / ntn);                 // m-tiles that fit in whole rounds
+            const int rows_main = m_main * 256;
+            GemmArgs head = a, tail = a;
+            head.M = rows_main; head.M_real = std::min(a.M_real, rows_main);
+            const size_t esz_out = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? 2 : 4;
+            tail.A = (const char *)a.A + (size_t)rows_main * a.lda * 2;
+            tail.out = (char *)a.out + (size_t)rows_main * a.ldo * esz_out;
+            tail.M = a.M - rows_main; tail.M_real = a.M_real - rows_main;
+            if (m_main >= 1 && rows_main < a.M && gemm_ring_supports(tail, 245)) {
+                hipError_t e = launch_wide(t, dtype, epi, head, stream);
+                if (e != hipSuccess) return e;
+                if (tail.M_real <= 0) return hipSuccess;
+                return launch_gemm_ring(t, dtype, epi, tail, 245, stream);
             }
-            return launch_wide(t, dtype, epi, a, stream);
         }
-        cfg = 245;
-        if (t.gemm_skinny && (long)(a.M / 128) * (a.N_pad / 256) < t.skinny_tiles && gemm_ring_supports(a, 122)) cfg = 122;
-        if (gemm_ring_supports(a, cfg)) return launch_gemm_ring(t, dtype, epi, a, cfg, stream);
+        return launch_wide(t, dtype, epi, a, stream);
     }
+    cfg = 245;
+    if ((long)(a.M / 128) * (a.N_pad / 256) < t.skinny_tiles && gemm_ring_supports(a, 122)) cfg = 122;
+    if (gemm_ring_supports(a, cfg)) return launch_gemm_ring(t, dtype, epi, a, cfg, stream);
     if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
     return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream, false) : launch_gemm_t<__bf16>(epi, a, stream, false);
 }
@@ -486,7 +476,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NKT <= 9 && NWAVES <= 4) ? 2 : 1) voi
                 mxs = fmaxf(mxs, s[kt][r]);
             }
         mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
-        const float nmx = -0.125f * mxs;
+        const float nmx = -AttnExp<T>::kScale * mxs;
         // e = round(exp(round(s/8 - max))) per ggml_soft_max, two keys per packed convert; exp(-inf) = 0 for padded keys.
         // The row sum adds the ROUNDED values (as ggml does) with one v_dot2c per pair.
         float sum = 0.0f;
@@ -495,10 +485,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NKT <= 9 && NWAVES <= 4) ? 2 : 1) voi
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[kt][r], 0.125f, nmx), __builtin_fmaf(s[kt][r + 1], 0.125f, nmx));
-                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[0], 1.44269504f, 0.0f));
-                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[1], 1.44269504f, 0.0f));
-                const typename Pair<T>::v2 eh = round_pair<T>(e0, e1);
+                const typename Pair<T>::v2 eh = AttnExp<T>::pair(s[kt][r], s[kt][r + 1], nmx);
                 sum = Pair<T>::sum2(eh, sum);
                 p[kt][r >> 3][r & 7] = eh[0]; p[kt][r >> 3][(r & 7) + 1] = eh[1];
             }
@@ -542,7 +529,7 @@ static hipError_t launch_attention_inst(const void *qkv, void *out, int n_img, i
     return hipGetLastError();
 }
 template <typename T>
-static hipError_t launch_attention_t(int attn_waves, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+static hipError_t launch_attention_t(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     const int nkt = (N + 31) / 32;
     switch (nkt) {
     case 1: return launch_attention_inst<T, 1, 1>(qkv, out, n_img, N, D, H, stream);
@@ -551,177 +538,14 @@ static hipError_t launch_attention_t(int attn_waves, const void *qkv, void *out,
     case 4: return launch_attention_inst<T, 4, 4>(qkv, out, n_img, N, D, H, stream);
     case 5: return launch_attention_inst<T, 5, 4>(qkv, out, n_img, N, D, H, stream);
     case 6: return launch_attention_inst<T, 6, 4>(qkv, out, n_img, N, D, H, stream);
-    case 7: {                                                                             // 197 tokens (224/16)
-        // 4 waves x 2 query tiles, two workgroups per CU (one stages K/V while the other computes): 109 us vs 124 us for
-        // one 7-wave workgroup per CU on 256 x 12 heads (VITX_ATTN_WAVES=7 keeps the latter for A/B runs)
-        return attn_waves == 7 ? launch_attention_inst<T, 7, 7>(qkv, out, n_img, N, D, H, stream) : launch_attention_inst<T, 7, 4>(qkv, out, n_img, N, D, H, stream);
-    }
+    // 197 tokens (224/16): 4 waves x 2 query tiles, two workgroups per CU (one stages K/V while the other computes): 109 us vs 124 us for
+    // one 7-wave workgroup per CU on 256 x 12 heads (r01)
+    case 7: return launch_attention_inst<T, 7, 4>(qkv, out, n_img, N, D, H, stream);
     case 9: return launch_attention_inst<T, 9, 4>(qkv, out, n_img, N, D, H, stream);      // 257 tokens (224/14)
     case 19: return launch_attention_inst<T, 19, 4>(qkv, out, n_img, N, D, H, stream);    // 577 tokens (384/16)
     default: return hipErrorInvalidValue;
     }
 }
-// ------------------------------------------------------------------------------------------------
-// Streaming attention for any token count (vit.cpp:826-866; the reference's DEFAULT hparams are patch 8 = 785 tokens,
-// vit.h:22-28): the single-pass kernel above keeps every key tile's scores in registers, which stops at 608 tokens and
-// is only instantiated for the token counts of the /16 models.  Here a workgroup owns 128 queries (4 waves x 32) of one
-// (image, head) and streams the keys through LDS in chunks of CH*32, TWICE:
-//   pass 1  S^T = K Q^T per chunk -> the row maximum over ALL keys (scores are discarded);
-//   pass 2  S^T again, e = round(exp(round(s/8 - max))) with that global maximum -- exactly ggml_soft_max's rounding points,
-//           no online rescaling -- row sum of the rounded e, O^T += V^T P^T; normalise at the end.
-// Recomputing QK^T costs 50 % more MFMA work than an online softmax, and keeps the numerics identical to the single-pass
-// kernel (same products, same rounding points, same summation order within a key tile; tiles are summed in order).
-// ------------------------------------------------------------------------------------------------
-template <typename T, int CH>
-__global__ __launch_bounds__(256, 2) void attention_stream_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int qblocks) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 256, CK = CH * 32, VLD = CK + 8;
-    char *Ks = smem;
-    T *VT = (T *)(smem + CK * 128);
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = blockIdx.x % qblocks, bh = blockIdx.x / qblocks;
-    const int b = bh / H, h = bh % H;
-    const T *base = qkv + (size_t)b * N * 3 * D + h * 64;
-    typedef typename Elem<T>::v8 v8;
-    const int nchunks = (N + CK - 1) / CK;
-
-    const int qrow = qb * 128 + wave * 32 + l31;
-    const bool qvalid = qrow < N;
-    v8 qf[4];
-    {
-        const int qr = min(qrow, N - 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qr * 3 * D + ks * 16 + hh * 8);
-    }
-    auto stage_k = [&](int key0) {
-        constexpr int IT = (CK * 8 + NT - 1) / NT;
-        v8 kv[IT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = it * NT + tid, key = key0 + (c >> 3), sl = c & 7;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) kv[it][j] = (T)0.0f;
-            if (c < CK * 8 && key < N) kv[it] = *(const v8 *)(base + (size_t)key * 3 * D + D + sl * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = it * NT + tid;
-            if (c < CK * 8) *(v8 *)(Ks + swz_byte(c >> 3, c & 7)) = kv[it];
-        }
-    };
-    auto stage_vt = [&](int key0) {      // V^T [64][CK + 8]; keys 4-7 <-> 8-11 of every 16 swapped (MFMA k-slot order of the P registers)
-        constexpr int NP = CK / 2, ITEMS = NP * 8, IT = (ITEMS + NT - 1) / NT;
-        v8 va[IT], vb[IT];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = it * NT + tid, pr = c % NP, sl = c / NP, key = key0 + 2 * pr;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { va[it][j] = (T)0.0f; vb[it][j] = (T)0.0f; }
-            if (c < ITEMS && key < N) va[it] = *(const v8 *)(base + (size_t)key * 3 * D + 2 * D + sl * 8);
-            if (c < ITEMS && key + 1 < N) vb[it] = *(const v8 *)(base + (size_t)(key + 1) * 3 * D + 2 * D + sl * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int c = it * NT + tid, pr = c % NP, sl = c / NP, key = 2 * pr;
-            if (c >= ITEMS) continue;
-            const int a = key & 15, q4 = a >> 2, q4s = (q4 == 1) ? 2 : (q4 == 2) ? 1 : q4;
-            const int pos = (key & ~15) | (q4s << 2) | (a & 3);
-            typedef T v2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) *(v2 *)(VT + (sl * 8 + j) * VLD + pos) = v2{va[it][j], vb[it][j]};
-        }
-    };
-    auto scores = [&](int kt, int key0, f32x16 &s) {      // one 32-key tile of S^T, padded keys masked
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const v8 kf = *(const v8 *)(Ks + swz_byte(kt * 32 + l31, ks * 2 + hh));
-            s = Elem<T>::mfma(kf, qf[ks], s);
-        }
-        if (key0 + kt * 32 + 32 > N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) if (key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) s[r] = -INFINITY;
-        }
-    };
-
-    // ---- pass 1: global row maximum of the raw scores
-    float mxs = -INFINITY;
-    for (int c = 0; c < nchunks; ++c) {
-        const int key0 = c * CK;
-        __syncthreads();
-        stage_k(key0);
-        __syncthreads();
-        const int nt = min(CH, (N - key0 + 31) / 32);
-        for (int kt = 0; kt < nt; ++kt) {
-            f32x16 s; scores(kt, key0, s);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mxs = fmaxf(mxs, s[r]);
-        }
-    }
-    mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
-    const float nmx = -0.125f * mxs;
-
-    // ---- pass 2: exponentials against the global maximum, row sum of the ROUNDED values, O^T = V^T P^T
-    float sum = 0.0f;
-    f32x16 o[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
-    for (int c = 0; c < nchunks; ++c) {
-        const int key0 = c * CK;
-        __syncthreads();
-        stage_k(key0); stage_vt(key0);
-        __syncthreads();
-        const int nt = min(CH, (N - key0 + 31) / 32);
-        for (int kt = 0; kt < nt; ++kt) {
-            f32x16 s; scores(kt, key0, s);
-            v8 p[2];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[r], 0.125f, nmx), __builtin_fmaf(s[r + 1], 0.125f, nmx));
-                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[0], 1.44269504f, 0.0f));
-                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[1], 1.44269504f, 0.0f));
-                const typename Pair<T>::v2 eh = round_pair<T>(e0, e1);
-                sum = Pair<T>::sum2(eh, sum);
-                p[r >> 3][r & 7] = eh[0]; p[r >> 3][(r & 7) + 1] = eh[1];
-            }
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const v8 vf = *(const v8 *)(VT + (dt * 32 + l31) * VLD + kt * 32 + half * 16 + hh * 8);
-                    o[dt] = Elem<T>::mfma(vf, p[half], o[dt]);
-                }
-        }
-    }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    if (qvalid) {
-        T *orow = out + ((size_t)b * N + qrow) * D + h * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                typename Elem<T>::v4 w4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w4[j] = (T)(o[dt][r4 * 4 + j] * inv);
-                *(typename Elem<T>::v4 *)(orow + dt * 32 + r4 * 8 + hh * 4) = w4;
-            }
-    }
-}
-template <typename T>
-static hipError_t launch_attention_stream(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
-    constexpr int CH = 8;
-    constexpr int lds = CH * 32 * 128 + 64 * (CH * 32 + 8) * 2;        // 32 KiB + 33 KiB
-    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_stream_kernel<T, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
-    const int qblocks = (N + 127) / 128;
-    hipLaunchKernelGGL((attention_stream_kernel<T, CH>), dim3(n_img * H * qblocks), dim3(256), lds, stream, (const T *)qkv, (T *)out, N, D, H, qblocks);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------
 // Pipelined two-pass attention (vit.cpp:826-866), any token count.  Same arithmetic as the two kernels above (same products,
 // rounding points and summation order: bit-identical results), laid out for latency hiding instead of register residency:
@@ -844,7 +668,7 @@ __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restr
 
     // ---- pass 2: exponentials against the global maximum, row sum of the ROUNDED values, O^T = V^T P^T
     float sum = 0.0f;
-    const float nmx = -0.125f * mxs;
+    const float nmx = -AttnExp<T>::kScale * mxs;
     f32x16 o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -861,9 +685,7 @@ __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restr
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[r], 0.125f, nmx), __builtin_fmaf(s[r + 1], 0.125f, nmx));
-                const f32x2 t = f32x2{(float)dh[0], (float)dh[1]} * f32x2{1.44269504f, 1.44269504f};
-                const typename Pair<T>::v2 eh = round_pair<T>(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
+                const typename Pair<T>::v2 eh = AttnExp<T>::pair(s[r], s[r + 1], nmx);
                 sum = Pair<T>::sum2(eh, sum);
                 p[r >> 3][r & 7] = eh[0]; p[r >> 3][(r & 7) + 1] = eh[1];
             }
@@ -943,83 +765,98 @@ template <typename T>
 static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream, int flags = 0) {
     switch (flags) {
     case 0: return launch_attention_flow_inst<T, 0>(qkv, out, n_img, N, D, H, stream);
+#ifdef VITX_LAB      // ablation builds of tools/attn_bench.py (results are garbage by design)
     case 1: return launch_attention_flow_inst<T, 1>(qkv, out, n_img, N, D, H, stream);
     case 2: return launch_attention_flow_inst<T, 2>(qkv, out, n_img, N, D, H, stream);
-    case 3: return launch_attention_flow_inst<T, 3>(qkv, out, n_img, N, D, H, stream);
     case 4: return launch_attention_flow_inst<T, 4>(qkv, out, n_img, N, D, H, stream);
     case 8: return launch_attention_flow_inst<T, 8>(qkv, out, n_img, N, D, H, stream);
-    case 12: return launch_attention_flow_inst<T, 12>(qkv, out, n_img, N, D, H, stream);
     case 16: return launch_attention_flow_inst<T, 16>(qkv, out, n_img, N, D, H, stream);
+#endif
     default: return hipErrorInvalidValue;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Persistent single-pass attention (vit.cpp:826-866) for 193..224 tokens -- ViT-*/16 at 224^2, the headline configuration.
-// Same arithmetic as attention_kernel (every score tile of a query in registers: same products, rounding points and summation
-// order, bit-identical results); what changes is how K and V reach the LDS.  The r01 ablation (profiles/r01_gemm_ablation.txt G)
-// attributes 40 % of the single-pass kernel to the K/V global loads of its register staging.  Here:
-//   * one persistent workgroup per CU, 8 waves, walks (image, head) items; wave w owns query tile w of the item (7 tiles: the eighth
-//     wave only moves data);
-//   * K (swizzled row image, permutation on the source side) and V (row-major) of item i + 1 land by LDS-DMA in a second 56 KiB
-//     buffer while item i is computed -- no staging registers, no VALU, no LDS transposition; the V^T fragments come out of
-//     ds_read_b64_tr_b16 exactly as in attention_flow_kernel;
+//   * one persistent workgroup per CU, 8 waves, walks (image, head) items; wave w owns queries 32 w .. 32 w + 31 of the item (7 waves
+//     compute, the eighth only moves data);
+//   * K (swizzled row image, permutation on the source side) and V (row-major, 32-byte chunks XOR-ed with (row >> 1) & 3) of item i + 1
+//     land by LDS-DMA in a second 56 KiB buffer while item i is computed -- no staging registers, no VALU, no LDS transposition;
+//   * products are v_mfma_f32_16x16x32 (r03; the GEMMs' instruction: 11 % less energy per flop than 32x32x16 on this part):
+//     S^T = K . Q^T as 16-key x 16-query tiles, so a query's scores sit in the 4 lanes (lane & 15, lane >> 4 = 0..3) and the softmax
+//     reductions are in-register plus two cross-row shuffles; the probabilities go from the accumulator registers straight into the
+//     B operand of O^T = V^T . P^T (k-slot j of lane group g = key 4 g + j of the first, 16 + 4 g + (j - 4) of the second 16-key tile
+//     of a 32-key step), and the V^T fragments in that same key order come out of two ds_read_b64_tr_b16 each;
+//   * key tiles and query tiles that hold no real token are skipped (197 tokens: 13 of 14 key tiles, 13 of 14 query tiles);
 //   * the DMA of the next item is issued AFTER the QK^T products (hipcc waits vmcnt(0) before the first use of the Q registers,
 //     which were loaded one item earlier: nothing else may be in flight then), so it has the softmax and the PV products to land;
 //     one barrier per item.
+// exp follows AttnExp<T> (device_common.h): F16 = ggml_soft_max's table semantics, BF16 = one f32 exp2 per key.
 // Keys 197..223 read the next image's rows (finite; masked to -inf) or the zeros a buffer load returns out of range.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NKT>
-__global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes) {
+__global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = NKT * 32, KB = NK * 128, BUF = 2 * KB;       // one item: K image + V image
     constexpr int PIECES = NK * 8, OPS = (PIECES + 511) / 512;      // 16-byte pieces per image, DMA instructions per thread and image
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+    constexpr int NT16 = NKT * 2;                                   // 16-key tiles
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef typename Elem<T>::v8 v8;
+    typedef typename Pair<T>::v2 v2;
     typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
     const int row_bytes = 3 * D * 2;
     const bool qwave = wave < NKT;
+    const bool two = wave * 32 + 16 < N;        // the wave's second 16-query tile holds at least one real query
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)qkv, 0, (int)total_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)out_bytes, 0x00020000);
     // (array bounds are a literal on purpose: hipcc drops the HOST stub of a template kernel -- no diagnostic, an undefined symbol at load
     // time -- when a lambda captures an array whose bound is a value-dependent constexpr local)
     static_assert(OPS <= 4, "at most 256 keys");
-    int koff[4], voff[4];
-#pragma unroll
-    for (int it = 0; it < OPS; ++it) {
-        const int p = it * 512 + tid;
-        int rr, sl; swz_inv(p, rr, sl);
-        koff[it] = rr * row_bytes + D * 2 + sl * 16;
-        const int vr = p >> 3, vs = (p & 7) ^ (((vr >> 1) & 1) << 2);           // V image: 16-B slot ^ 4 on rows 2, 3 (mod 4)
-        voff[it] = vr * row_bytes + 2 * D * 2 + vs * 16;
-    }
     auto item_base = [&](int item) { const int b = item / H, h = item - b * H; return (int)(((size_t)b * N * 3 * D + h * 64) * 2); };     // bytes (< 4 GiB: launcher)
+    // DMA piece it * 512 + tid of an image is image row (64 it + row of piece tid), same 16-byte slot: ONE per-lane offset per image and an
+    // SGPR stride (the kernel sits at the 256-register limit: eight per-piece offsets were spilled, and every reload is a vector-memory
+    // op that drains the DMA queue before the next piece)
+    int koff0, voff0;
+    {
+        int rr, sl; swz_inv(tid, rr, sl);
+        koff0 = rr * row_bytes + D * 2 + sl * 16;
+        const int vr = tid >> 3, vs = (tid & 7) ^ (((vr >> 1) & 3) << 1);          // V image: 32-byte chunk ^ ((row >> 1) & 3); rows 64 it + vr share it
+        voff0 = vr * row_bytes + 2 * D * 2 + vs * 16;
+    }
     auto stage = [&](int item, char *buf) {
         const int so = __builtin_amdgcn_readfirstlane(item_base(item));
 #pragma unroll
         for (int it = 0; it < OPS; ++it) {
             if (it * 512 + wave * 64 < PIECES) {            // wave-uniform: the last instruction covers only part of the image
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + it * 8192 + wave * 1024), 16, koff[it], so, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + it * 8192 + wave * 1024), 16, voff[it], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + it * 8192 + wave * 1024), 16, koff0, so + it * 64 * row_bytes, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + it * 8192 + wave * 1024), 16, voff0, so + it * 64 * row_bytes, 0, 0);
             }
         }
     };
-    v8 qf[4];
+    // Q fragments (B operand of S^T = K . Q^T): lane (l15 = query of the tile, g4) holds dims k2 * 32 + g4 * 8 .. + 7
+    v8 qf[2][2];
     auto load_q = [&](int item) {
         const T *base = qkv + (size_t)item_base(item) / 2;
-        const int qrow = min(wave * 32 + l31, N - 1);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8 *)(base + (size_t)qrow * 3 * D + ks * 16 + hh * 8);
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qrow = min(wave * 32 + qt * 16 + l15, N - 1);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) qf[qt][k2] = *(const v8 *)(base + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8);
+        }
     };
-    // fragment addresses (kernel attention_flow_kernel): K tile kt adds kt * 4096, V tile kt adds kt * 32 * 128
-    int krd[4], vrd[2];
+    // fragment addresses: K tile t (16 keys) = parity (t & 1) base + (t >> 1) * 4096; V step ks (32 keys) adds ks * 4096, its second half 2048
+    int krd[2][2], vrd[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) krd[ks] = swz_byte(l31, ks * 2 + hh);
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) krd[pz][k2] = swz_byte(pz * 16 + l15, k2 * 4 + g4);
     {
-        const int r = 4 * hh + ((lane & 15) >> 2), rb = (r >> 1) & 1;
+        const int r = 4 * g4 + (l15 >> 2), x = (r >> 1) & 3;       // this lane's V row within a 16-key group and its chunk swizzle
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) vrd[dt] = KB + r * 128 + ((dt ^ rb) << 6) + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+        for (int dt = 0; dt < 4; ++dt) vrd[dt] = KB + r * 128 + ((dt ^ x) << 5) + (l15 & 3) * 8;
     }
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char *)smem);
 
@@ -1035,91 +872,105 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__re
         const char *cur = smem + cur_off;
         const int b = item / H, h = item - b * H;
         const int nitem = item + gridDim.x;
-        f32x16 s[NKT];
+        f32x4 s[14][2];
+        static_assert(NT16 == 14, "literal array bound above");
         if (qwave) {
             // S^T tiles: rows = keys, cols = queries
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
+            for (int t = 0; t < NT16; ++t) {
+                if (t * 16 < N) {                   // wave-uniform: a tile of padded keys only is never multiplied
+                    const v8 k0 = *(const v8 *)(cur + krd[t & 1][0] + (t >> 1) * 4096), k1 = *(const v8 *)(cur + krd[t & 1][1] + (t >> 1) * 4096);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.0f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s[kt] = Elem<T>::mfma(*(const v8 *)(cur + krd[ks] + kt * 4096), qf[ks], s[kt]);
+                    for (int qt = 0; qt < 2; ++qt) {
+                        if (qt == 0 || two) {
+                            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                            acc = Elem<T>::mfma16(k0, qf[qt][0], acc);
+                            s[t][qt] = Elem<T>::mfma16(k1, qf[qt][1], acc);
+                        }
+                    }
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (nitem < items) { stage(nitem, smem + (cur_off ^ BUF)); if (qwave) load_q(nitem); }      // lands during the softmax and the PV products
+        if (nitem < items) stage(nitem, smem + (cur_off ^ BUF));      // lands during the softmax and the PV products
         __builtin_amdgcn_sched_barrier(0);
         if (qwave) {
-            const int qrow = wave * 32 + l31;
-            float mxs = -INFINITY;
+            v8 p[7][2];
+            float inv[2] = {0.0f, 0.0f};
+            static_assert(NKT == 7, "literal array bound above");
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
+            for (int qt = 0; qt < 2; ++qt) {
+                if (qt == 0 || two) {
+                    float mxs = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (kt == NKT - 1) {       // only the last key tile can hold padded keys
-                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (key >= N) s[kt][r] = -INFINITY;
+                    for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (t >= 12) {       // only the last two 16-key tiles can hold padded keys (N > 192)
+                                const int key = t * 16 + 4 * g4 + r;
+                                if (key >= N) s[t][qt][r] = -INFINITY;
+                            }
+                            mxs = fmaxf(mxs, s[t][qt][r]);
+                        }
+                    mxs = fmaxf(mxs, __shfl_xor(mxs, 16));
+                    mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+                    const float nmx = -AttnExp<T>::kScale * mxs;
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < NKT; ++ks) {      // numerators per AttnExp<T>; row sum of the ROUNDED values (they are what the PV product sees)
+                        const v2 e0 = AttnExp<T>::pair(s[2 * ks][qt][0], s[2 * ks][qt][1], nmx), e1 = AttnExp<T>::pair(s[2 * ks][qt][2], s[2 * ks][qt][3], nmx);
+                        const v2 e2 = AttnExp<T>::pair(s[2 * ks + 1][qt][0], s[2 * ks + 1][qt][1], nmx), e3 = AttnExp<T>::pair(s[2 * ks + 1][qt][2], s[2 * ks + 1][qt][3], nmx);
+                        sum = Pair<T>::sum2(e0, sum); sum = Pair<T>::sum2(e1, sum); sum = Pair<T>::sum2(e2, sum); sum = Pair<T>::sum2(e3, sum);
+                        p[ks][qt] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
                     }
-                    mxs = fmaxf(mxs, s[kt][r]);
+                    sum += __shfl_xor(sum, 16);
+                    sum += __shfl_xor(sum, 32);
+                    inv[qt] = 1.0f / sum;
                 }
-            mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
-            const float nmx = -0.125f * mxs;
-            float sum = 0.0f;
-            v8 p[NKT][2];
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {      // e = round(exp(round(s/8 - max))) per ggml_soft_max; row sum of the ROUNDED values
-                    const typename Pair<T>::v2 dh = round_pair<T>(__builtin_fmaf(s[kt][r], 0.125f, nmx), __builtin_fmaf(s[kt][r + 1], 0.125f, nmx));
-                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[0], 1.44269504f, 0.0f));
-                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf((float)dh[1], 1.44269504f, 0.0f));
-                    const typename Pair<T>::v2 eh = round_pair<T>(e0, e1);
-                    sum = Pair<T>::sum2(eh, sum);
-                    p[kt][r >> 3][r & 7] = eh[0]; p[kt][r >> 3][(r & 7) + 1] = eh[1];
-                }
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            // O^T = V^T . P^T: rows = head dims (2 tiles of 32), cols = queries; V^T fragments by transposed LDS reads (inline asm: behind the
-            // builtin hipcc waits vmcnt(0) in front of every transposed read while the next item's LDS-DMA is in flight)
-            f32x16 o[2];
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] = 0.0f;
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                const unsigned cb = lds0 + (unsigned)cur_off + kt * 32 * 128;
-                s4 f[2][2][2];
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const unsigned va = cb + vrd[dt];
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt][0][0]) : "v"(va));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(f[dt][0][1]) : "v"(va));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[dt][1][0]) : "v"(va));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:3072" : "=v"(f[dt][1][1]) : "v"(va));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]),
-                                                      "+v"(f[1][0][0]), "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]));
-                typedef short s8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const s8 both = __builtin_shufflevector(f[dt][half][0], f[dt][half][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        o[dt] = Elem<T>::mfma(__builtin_bit_cast(v8, both), p[kt][half], o[dt]);
-                    }
             }
-            if (qrow < N) {
-                T *orow = out + ((size_t)b * N + qrow) * D + h * 64;
+            // the next item's Q fragments: issued here (after the scores died: 16 registers the softmax needs) and in flight under the PV products
+            __builtin_amdgcn_sched_barrier(0);
+            if (nitem < items) load_q(nitem);
+            __builtin_amdgcn_sched_barrier(0);
+            // O^T = V^T . P^T: rows = head dims (4 tiles of 16), cols = queries; V^T fragments by transposed LDS reads (inline asm: behind the
+            // builtin hipcc waits vmcnt(0) in front of every transposed read while the next item's LDS-DMA is in flight)
+            f32x4 o[4][2];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        typename Elem<T>::v4 w4;
+                for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w4[j] = (T)(o[dt][r4 * 4 + j] * inv);
-                        *(typename Elem<T>::v4 *)(orow + dt * 32 + r4 * 8 + hh * 4) = w4;
-                    }
+            for (int ks = 0; ks < NKT; ++ks) {
+                const unsigned cb = lds0 + (unsigned)cur_off + ks * 4096;
+                s4 f[4][2];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const unsigned va = cb + vrd[dt];
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt][0]) : "v"(va));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[dt][1]) : "v"(va));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]),
+                                                      "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]));
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const s8 both = __builtin_shufflevector(f[dt][0], f[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        if (qt == 0 || two) o[dt][qt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p[ks][qt], o[dt][qt]);
+                }
+            }
+            // lane (l15 = query, g4) holds O[query][dt * 16 + 4 g4 .. + 3]: 8 bytes per (dt, qt); rows past N go out of the buffer's range and
+            // are dropped, so every computing wave issues exactly 8 stores per item (the counted wait below relies on it)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {             // also for a second tile without real queries (zeros, all dropped): a uniform store count
+                const int qrow = wave * 32 + qt * 16 + l15;
+                const unsigned off = qrow < N ? (unsigned)((((size_t)b * N + qrow) * D + h * 64 + g4 * 4) * 2) : 0xfffffff0u;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const v2 lo = round_pair<T>(o[dt][qt][0] * inv[qt], o[dt][qt][1] * inv[qt]), hi = round_pair<T>(o[dt][qt][2] * inv[qt], o[dt][qt][3] * inv[qt]);
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, rsrc_o, (int)(off + (qrow < N ? dt * 32 : 0)), 0, 0);
+                }
             }
         }
         // The next item's K / V and Q must have landed; this wave's 8 output stores are YOUNGER than those loads and may stay in flight
@@ -1137,7 +988,7 @@ static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img
     if (total >= 0xf0000000u) return hipErrorInvalidValue;          // 32-bit buffer offsets
     const int items = n_img * H;
     const int grid = items < n_cu ? items : n_cu;
-    hipLaunchKernelGGL((attention_persist_kernel<T, NKT>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total);
+    hipLaunchKernelGGL((attention_persist_kernel<T, NKT>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
     return hipGetLastError();
 }
 bool attention_persist_supports(int n_img, int N, int D) { return N > 192 && N <= 224 && (size_t)n_img * N * 3 * D * 2 < 0xf0000000u; }
@@ -1150,22 +1001,21 @@ bool attention_single_pass_supports(int N) {
 }
 bool attention_supports(int N, int D, int H) { return D == H * 64 && N > 0; }      // any token count
 // Kernel choice (measured, 128 x 12 heads bf16: 197 tokens 52 vs 55 us, 257 tokens 77 vs 92 us single-pass vs pipelined;
-// 64 x 16 heads x 577 tokens 282 vs 241 us; 785 tokens: streaming 66 vs pipelined 44 us -- profiles/r02_attention.txt):
-//   single-pass (all scores in registers) up to 288 tokens where instantiated, the pipelined two-pass kernel for everything else.
-// VITX_ATTN_WAVES: 0 forces the streaming kernel, -1 the pipelined one, 7 the 7-wave single-pass build for 197 tokens.
+// 64 x 16 heads x 577 tokens 282 vs 241 us -- profiles/r02_attention.txt):
+//   193..224 tokens with at least two items per CU: the persistent single-pass kernel; otherwise single-pass (all scores in registers)
+//   up to 288 tokens where instantiated, the pipelined two-pass kernel for everything else.
+// t.attn_kernel (vitx_op_attention_ex, tests): ATTN_SINGLE / ATTN_FLOW / ATTN_PERSIST force one family.
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
-    if (t.attn_waves == 0)
-        return dtype == DT_F16 ? launch_attention_stream<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_stream<__bf16>(qkv, out, n_img, N, D, H, stream);
     // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax); needs
     // enough items to keep every workgroup busy for a few rounds, otherwise the one-item-per-workgroup kernel starts faster
-    if ((t.attn_waves == -3 || (t.attn_persist && t.attn_waves == 4 && (long)n_img * H >= 2L * t.n_cu)) && attention_persist_supports(n_img, N, D))
+    if ((t.attn_kernel == ATTN_PERSIST || (t.attn_kernel == ATTN_AUTO && (long)n_img * H >= 2L * t.n_cu)) && attention_persist_supports(n_img, N, D))
         return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.n_cu, stream) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.n_cu, stream);
-    const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_waves == -2);      // -2: vitx_op_attention_ex(kernel 1)
-    if (t.attn_waves == -1 || !single)
+    if (t.attn_kernel == ATTN_PERSIST) return hipErrorInvalidValue;
+    const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_kernel == ATTN_SINGLE);
+    if (t.attn_kernel == ATTN_FLOW || !single)
         return dtype == DT_F16 ? launch_attention_flow<_Float16>(qkv, out, n_img, N, D, H, stream, t.attn_flags) : launch_attention_flow<__bf16>(qkv, out, n_img, N, D, H, stream, t.attn_flags);
-    const int waves = t.attn_waves > 0 ? t.attn_waves : 4;
-    return dtype == DT_F16 ? launch_attention_t<_Float16>(waves, qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(waves, qkv, out, n_img, N, D, H, stream);
+    return dtype == DT_F16 ? launch_attention_t<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_t<__bf16>(qkv, out, n_img, N, D, H, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1177,20 +1027,15 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
     for (int dt = 0; dt < 2; ++dt) {
         for (int epi = 0; epi <= EPI_PATCH; ++epi) {
             for (int cfg : {945, 445, 245, 122}) if ((e = launch_gemm_ring(t, dt, epi, none, cfg, nullptr, true)) != hipSuccess) return e;
-            for (int fl : {0, 4096, 8192}) if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, fl, true)) != hipSuccess) return e;
-            if (epi == EPI_BIAS_RESID) { GemmArgs f{}; f.ln_out = (void *)1; f.ln_cnt = (int *)1; f.ln_w = f.ln_b = (const float *)1; f.N = f.ldo = 256; if ((e = launch_gemm_pp(dt, epi, f, t.n_cu, nullptr, 32768, true)) != hipSuccess) return e; }
+            if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16, true>(epi, none, nullptr, true) : launch_gemm_t<__bf16, true>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
-        if ((e = (dt == DT_F16 ? launch_attention_stream<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_stream<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_flow<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_flow<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_persist<_Float16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr) : launch_attention_persist<__bf16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr))) != hipSuccess) return e;
         for (int nkt : kAttnNkt) {
-            for (int w : {4, 7}) {
-                if (w == 7 && nkt != 7) continue;
-                e = dt == DT_F16 ? launch_attention_t<_Float16>(w, nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr) : launch_attention_t<__bf16>(w, nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr);
-                if (e != hipSuccess) return e;
-            }
+            e = dt == DT_F16 ? launch_attention_t<_Float16>(nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr) : launch_attention_t<__bf16>(nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr);
+            if (e != hipSuccess) return e;
         }
     }
     return hipSuccess;
@@ -1208,21 +1053,18 @@ const Tuning *tuning_for_device(int device) {
     std::unique_ptr<Tuning> t(new Tuning());
     t->device = device;
     if (hipDeviceGetAttribute(&t->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || t->n_cu <= 0) t->n_cu = 256;
+#ifdef VITX_LAB      // the laboratory build (tools/) reads its experiment switches from the environment; the product library reads none of them
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
-    if (const char *e = getenv("VITX_GEMM_CFG")) t->gemm_cfg = !strcmp(e, "v1") ? 0 : (!strcmp(e, "pp") ? 1 : atoi(e));
-    t->gemm_pp = env_int("VITX_GEMM_PP", 1);
-    t->gemm_stream = env_int("VITX_GEMM_STREAM", 1);
-    t->gemm_skinny = getenv("VITX_GEMM_NOSKINNY") == nullptr;
-    t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);      // r02: with the persistent ping-pong kernel the two-launch tail split costs 5 % of the step (profiles/r02_forward_sweeps.txt)
+    if (const char *e = getenv("VITX_GEMM_CFG")) t->gemm_cfg = !strcmp(e, "pp") ? 1 : atoi(e);
+    t->gemm_split = env_int("VITX_GEMM_SPLIT", 0);
     t->gemm_balance = env_int("VITX_GEMM_BALANCE", 1);
-    t->pp_flags = env_int("VITX_PP_SCHED", 4) == 2 ? 4096 : (env_int("VITX_PP_SCHED", 4) == 8 ? 8192 : (env_int("VITX_PP_SCHED", 4) == 32 ? 65536 : 0));
     t->group_m = env_int("VITX_GROUP_M", 0);
     t->skinny_tiles = env_int("VITX_SKINNY_TILES", 128);
-    t->ln_fuse = env_int("VITX_LN_FUSE", 1);
-    t->pp_dbg = env_int("VITX_PP_DBG", 0);
+    t->pp_flags = env_int("VITX_PP_FLAGS", 0);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
-    t->attn_waves = env_int("VITX_ATTN_WAVES", 4);
-    t->attn_persist = env_int("VITX_ATTN_PERSIST", 1);
+    t->attn_kernel = env_int("VITX_ATTN_KERNEL", 0);
+    t->ln_fuse = env_int("VITX_LN_FUSE", 1);
+#endif
     const hipError_t e = prepare_device_kernels(*t);
     if (cur != device) (void)hipSetDevice(cur);
     if (e != hipSuccess) return nullptr;

@@ -11,6 +11,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <atomic>
 #include <string.h>
 
 #include <algorithm>
@@ -206,10 +207,13 @@ int vitx_model_load(const char *path, vitx_model **out) {
     if (!m) return VITX_ERR_NOMEM;
     const int rc = vitx::load_impl(path, *m);
     if (rc != VITX_OK) return rc;
+    static std::atomic<uint64_t> next_uid{1};
+    m->uid = next_uid.fetch_add(1);
     *out = m.release();
     return VITX_OK;
 }
 void vitx_model_free(vitx_model *m) { delete m; }
+uint64_t vitx_model_uid(const vitx_model *m) { return m ? m->uid : 0; }
 int vitx_model_hparams(const vitx_model *m, vitx_hparams *out) {
     if (!m || !out) return VITX_ERR_ARG;
     *out = m->hp; return VITX_OK;

@@ -29,6 +29,7 @@ struct HostTensor {
 
 struct vitx_model {
     vitx_hparams hp;
+    uint64_t uid = 0;                                 // unique per successful vitx_model_load in this process (never reused: an address can be)
     int in_chans = 3;                                 // 1 = ViTSTR file (grey input, sequence head), from the patch kernel's shape
     std::map<int, std::string> id2label;
     std::vector<vitx::HostTensor> tensors;            // file order

@@ -58,13 +58,13 @@ bool vit_image_preprocess(const image_u8 &img, image_f32 &res, const vit_hparams
 }
 
 // The reference's vit_state carries no weights and can be reused with any model; ours caches a context that does, so the cache
-// is keyed on the parsed model it was built from (vit_model_load frees and replaces that handle on every call).
+// is keyed on the unique id of the parsed model it was built from (vit_model_load frees and replaces that handle on every call).
 static int ensure_ctx(const vit_model &model, vit_state &state, int n) {
-    if (state.ctx && state.ctx_model == model.handle && vitx_ctx_max_batch(state.ctx) >= n) return VITX_OK;
-    vitx_ctx_free(state.ctx); state.ctx = nullptr; state.ctx_model = nullptr;
+    if (state.ctx && state.ctx_model_uid == vitx_model_uid(model.handle) && vitx_ctx_max_batch(state.ctx) >= n) return VITX_OK;
+    vitx_ctx_free(state.ctx); state.ctx = nullptr; state.ctx_model_uid = 0;
     state.max_batch = std::max(state.max_batch, n);
     const int rc = vitx_ctx_create(model.handle, state.device, state.max_batch, state.dtype, &state.ctx);
-    if (rc == VITX_OK) state.ctx_model = model.handle;
+    if (rc == VITX_OK) state.ctx_model_uid = vitx_model_uid(model.handle);
     return rc;
 }
 

@@ -51,8 +51,9 @@ struct vit_model {                        // vit.h:82-89 (tensor handles replace
 
 struct vit_state {                        // vit.h:72-80: per-caller mutable scratch
     vitx_ctx *ctx = nullptr;              // created lazily by vit_predict on `device`
-    const vitx_model *ctx_model = nullptr; // the parsed file `ctx` holds the weights of: a state reused with another (or a reloaded)
-                                          // vit_model gets a fresh context instead of silently running the old weights
+    uint64_t ctx_model_uid = 0;           // vitx_model_uid of the parsed file `ctx` holds the weights of: a state reused with another (or a
+                                          // reloaded) vit_model gets a fresh context instead of silently running the old weights.  An id,
+                                          // not the pointer: `vit_model m; vit_model_load(f, m);` in a loop usually re-allocates the same address
     int device = 0;
     int max_batch = 1;                    // capacity of ctx; grown on demand by vit_predict_batch
     int dtype = VITX_F16;                 // MFMA operand type (VITX_F16 reproduces the reference's rounding)
