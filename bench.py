@@ -10,11 +10,18 @@ synthetic 224x224x3 images already resident in HBM, through the C ABI of libvitx
 N>1: one process per GPU, images sharded by batch (weak scaling: 256 per GPU), weights
 replicated, and ONE RCCL all-gather of the [256,1000] class probabilities per step.
 Prints one JSON line (rank 0).
+
+The line is self-verifying (r02 verdict): the probabilities of the timed configuration are compared with the CPU oracle on
+a sample of the batch ("parity"), the run is refused when a development override is in the environment, and -- after the
+primary timed region, outside `value` -- the same process measures the F16 parity mode, a >= 3 s sustained run with
+package power / clock samples, and short lines for BASELINE.json's configs 3 (ViT-L/16-384 bs 128) and 5 (q4_0 file).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 2516.6      # dense bf16/fp16 MFMA, 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH: ~2.5 PF)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+FTYPES = {"f16": 1, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}
 
 
 def load_traffic():
@@ -36,6 +44,57 @@ def load_traffic():
         return {}, None
 
 
+def development_overrides():
+    """Environment switches that would make the number something other than the product's: the library itself reads none
+    (vitx_ctx_options is the only knob), but VITX_LIB makes binding.py load ANOTHER library (the -DVITX_LAB build honours VITX_SKIP,
+    VITX_*_DBG ...), so any VITX_* variable except the two this script defines is treated as an override."""
+    allowed = {"VITX_FORCE_DIST", "VITX_CACHE"}
+    return sorted(k for k in os.environ if k.startswith("VITX_") and k not in allowed)
+
+
+class SmiSampler:
+    """Package power / shader clock while a timed loop runs: `rocm-smi --showpower --showclocks --json` every ~0.4 s from a thread.
+    Informative only: any failure yields None."""
+
+    def __init__(self, device):
+        self.device, self.samples, self._stop, self._t = device, [], threading.Event(), None
+
+    def _one(self):
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            d = json.loads(out)
+            card = d[sorted(d)[0]]
+            w = mhz = None
+            for k, v in card.items():
+                kl = k.lower()
+                if "power" in kl and "(w)" in kl and w is None:
+                    w = float(v)
+                if kl.startswith("sclk clock speed"):
+                    mhz = float(str(v).strip("()").lower().replace("mhz", ""))
+            if w is not None:
+                self.samples.append((w, mhz))
+        except Exception:
+            pass
+
+    def __enter__(self):
+        def loop():
+            while not self._stop.is_set():
+                self._one()
+                self._stop.wait(0.4)
+        self._t = threading.Thread(target=loop, daemon=True); self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set(); self._t.join(timeout=6)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        ws = [s[0] for s in self.samples]; cs = [s[1] for s in self.samples if s[1]]
+        return {"samples": len(ws), "package_W_mean": round(sum(ws) / len(ws), 1), "package_W_max": round(max(ws), 1),
+                "shader_MHz_mean": round(sum(cs) / len(cs)) if cs else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,12 +103,18 @@ def main():
     ap.add_argument("--model", default="vit_base_patch16_224")
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (cpu_baseline AND parity)")
     ap.add_argument("--cpu-images", type=int, default=48, help="images of the batch timed through the CPU oracle (~10-15 s on the 128-thread GPU host)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
-    ap.add_argument("--ftype", default="f16", choices=["f16", "q4_0", "q4_1", "q5_0", "q5_1", "q8_0"], help="weight file type (BASELINE config 5: q4_0)")
+    ap.add_argument("--ftype", default="f16", choices=sorted(FTYPES), help="weight file type (BASELINE config 5: q4_0)")
     ap.add_argument("--no-host-feed", action="store_true", help="skip the secondary u8-from-host measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements after the timed region (f16 parity mode, sustained run, configs 3 and 5)")
+    ap.add_argument("--allow-overrides", action="store_true", help="run although a VITX_* development override is set; the line is stamped invalid")
     args = ap.parse_args()
+
+    overrides = development_overrides()
+    if overrides and not args.allow_overrides:
+        raise SystemExit(f"bench.py refuses to measure with development overrides in the environment: {overrides} (--allow-overrides stamps the line invalid instead)")
 
     import numpy as np
     import torch
@@ -73,7 +138,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # weights: random-init of the named architecture in the reference's file format
-    ftype = {"f16": 1, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}[args.ftype]
+    ftype = FTYPES[args.ftype]
     if rank == 0:
         path = pkg.synth.cached_synthetic(args.model, ftype=ftype, head_scale=8.0)
     if dist is not None:
@@ -92,7 +157,6 @@ def main():
     u8 = torch.randint(0, 256, (B, S, S, 3), generator=g, dtype=torch.uint8)
     mean = torch.tensor(pkg.synth.IMAGENET_MEAN); std = torch.tensor(pkg.synth.IMAGENET_STD)
     imgs = ((u8.float() - mean) / std).contiguous().cuda()
-    if os.environ.get('BENCH_RANDN'): imgs = torch.randn_like(imgs)
     probs = torch.empty((B, C), dtype=torch.float32, device="cuda")
     # Everything of a step is enqueued on ONE explicit (non-default) torch stream whose handle the engine gets: the forward, and
     # after it -- ordered by that stream -- the RCCL all-gather.  (The legacy null stream's handle is 0, which the C ABI reads as
@@ -137,6 +201,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    sanity = probs.sum(1)
+    assert torch.isfinite(probs).all() and float((sanity - 1).abs().max()) < 1e-3, "forward produced invalid probabilities"
+    if dist is not None:      # the gathered tensor must hold THIS step's local probabilities in this rank's shard
+        mine = state["all"][rank * B:(rank + 1) * B]
+        assert torch.equal(mine, probs), "all-gather returned stale or foreign probabilities for this rank's shard"
+        assert float((state["all"].sum(1) - 1).abs().max()) < 1e-3, "a gathered shard holds invalid probabilities"
+    timed_probs = probs.cpu().numpy()            # the probabilities the timed region produced (parity is checked on THESE)
+
+    def quick_rate(c, n_img, d_in, d_out, steps, warm=2):
+        """images/s of `steps` forwards of context c (secondary measurements: no profiling, no collective)."""
+        for _ in range(warm):
+            with torch.cuda.stream(st):
+                c.forward_device(d_in.data_ptr(), n_img, d_out.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        q0 = time.perf_counter()
+        for _ in range(steps):
+            with torch.cuda.stream(st):
+                c.forward_device(d_in.data_ptr(), n_img, d_out.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        dtq = time.perf_counter() - q0
+        return n_img * steps / dtq, dtq / steps * 1e3
+
     # secondary, NOT the metric: the same step fed from host memory -- u8 images in pinned RAM -> H2D -> device-side
     # vit_image_preprocess (bicubic, here 224 -> 224) -> forward; PCIe-inclusive rate for DESIGN.md
     host_feed = None
@@ -144,11 +230,12 @@ def main():
         u8_pinned = u8.pin_memory()
         d_u8 = torch.empty_like(u8, device="cuda")
         imgs2 = torch.empty_like(imgs)
+        probs2 = torch.empty_like(probs)
         def fed_step():
             with torch.cuda.stream(st):          # copy, preprocess and forward are ordered by the one stream
                 d_u8.copy_(u8_pinned, non_blocking=True)
                 binding.preprocess_device(d_u8.data_ptr(), B, S, S, S, imgs2.data_ptr(), binding.BICUBIC, stream)
-                ctx.forward_device(imgs2.data_ptr(), B, probs.data_ptr(), 0, stream)
+                ctx.forward_device(imgs2.data_ptr(), B, probs2.data_ptr(), 0, stream)
         for _ in range(2): fed_step()
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
@@ -156,15 +243,7 @@ def main():
         for _ in range(nfed): fed_step()
         torch.cuda.synchronize()
         host_feed = B * nfed / (time.perf_counter() - tf0)
-        # restore the probabilities of the resident batch for the sanity check below
-        step(); torch.cuda.synchronize()
-
-    sanity = probs.sum(1)
-    assert torch.isfinite(probs).all() and float((sanity - 1).abs().max()) < 1e-3, "forward produced invalid probabilities"
-    if dist is not None:      # the gathered tensor must hold THIS step's local probabilities in this rank's shard
-        mine = state["all"][rank * B:(rank + 1) * B]
-        assert torch.equal(mine, probs), "all-gather returned stale or foreign probabilities for this rank's shard"
-        assert float((state["all"].sum(1) - 1).abs().max()) < 1e-3, "a gathered shard holds invalid probabilities"
+        del d_u8, imgs2, probs2
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -179,15 +258,15 @@ def main():
             "gflop_per_image": round(gflop, 4), "weights": args.ftype,
             "weight_bytes_hbm": ctx.weight_bytes(),
             "weight_path": ("16-bit operand matrices resident in HBM" if args.ftype == "f16" else
-                            ("expanded once on the host at upload (VITX_QUANT_HOST=1)" if os.environ.get("VITX_QUANT_HOST") else
-                             f"{args.ftype} blocks resident in HBM; each layer's matrices expanded on the device just in time (dequant_kernel, quant.hip) into a "
-                             "per-stream scratch, then the same wide-tile MFMA kernels as the f16 file (q4_0 GEMMs of <= VITX_Q4_FUSED_ROWS rows expand "
-                             "inside the GEMM instead)")),
+                            f"{args.ftype} blocks resident in HBM; each layer's matrices expanded on the device just in time (dequant_kernel, quant.hip) into a "
+                            "per-stream scratch, then the same wide-tile MFMA kernels as the f16 file"),
             "mfma_roofline_frac_whole_forward": round(value / world * gflop / 1e3 / PEAK_TFLOPS, 4),
+            "library": os.path.relpath(binding.LIB_PATH, ROOT),
         }
+        if overrides:
+            out["invalid"] = f"development overrides in the environment: {overrides}"
         # roofline of the dominant kernel: algorithmic flops / HIP-event time on the launch stream
         if prof:
-            kern = {p["name"]: p for p in prof}
             gemms = [p for p in prof if p["name"].startswith("gemm_")]
             # busy_ms = wall time during which >= 1 launch of the class ran; profiled steps are single-stream, so it equals
             # the sum of the (exclusive) launch durations
@@ -201,7 +280,7 @@ def main():
             # what the matrix pipe of THIS device sustains on non-trivial operand values under its power cap (vitx_probe_mfma:
             # back-to-back MFMAs on register operands, uniform random fill, no memory traffic): `peak` above stays the nominal
             # 2516.6 TFLOP/s the contract asks for; this is the measured ceiling the same silicon reaches in the best case
-            if world == 1 and not os.environ.get("VITX_NO_MFMA_PROBE"):
+            if world == 1:
                 try:
                     ptf, pmhz = binding.probe_mfma(local_rank, dt, 2, 150.0)
                     out["roofline"]["mfma_sustained_random_operands"] = {
@@ -215,21 +294,88 @@ def main():
             out["roofline"]["measured_over"] = f"last {prof_steps} of the {args.steps} timed steps"
             out["roofline"]["schedule"] = "profiled steps: sub-batches serialised on one stream; other steps: 2 sub-batches on 2 HIP streams"
             tot = sum(p["busy_ms"] for p in prof)
-            out["kernel_breakdown"] = {p["name"]: {"busy_ms_per_step": round(p["busy_ms"] / prof_steps, 4), "share": round(p["busy_ms"] / tot, 4),
+            out["kernel_breakdown"] = {p["name"]: {"busy_ms_per_step": round(p["busy_ms"] / prof_steps, 4), "share": round(p["busy_ms"] / tot, 4), "launches": p["launches"] // prof_steps,
                                                     "TFLOPs": round(p["flops"] / (p["busy_ms"] * 1e-3) / 1e12, 1) if p["flops"] else None,
                                                     "GBps_algorithmic": round(p["bytes"] / (p["busy_ms"] * 1e-3) / 1e9, 1)} for p in prof}
         if host_feed is not None:
             out["host_fed_images_per_s"] = {"value": round(host_feed, 1), "what": "secondary, not the metric: u8 batch in pinned host RAM -> H2D (PCIe) -> device bicubic preprocess -> forward, serial on one stream"}
+
+        # ---- parity of the timed configuration + the CPU baseline (the oracle is the checker and the baseline, never the product)
+        oracle_rows = None
         if world == 1 and not args.no_cpu_baseline:
+            import dataclasses
             from oracle import oracle as O
             om = O.OracleModel(path)
-            n_cpu = args.cpu_images
+            n_cpu = min(args.cpu_images, B)
             cpu_imgs = imgs[:n_cpu].cpu().numpy()
+            quant = args.ftype != "f16"
             t1 = time.perf_counter()
-            om.forward(cpu_imgs, O.REF)
+            _, ref_p = om.forward(cpu_imgs, O.REF)                     # the reference's semantics (ggml rounding points; q8_0 activations on a quantised file)
             dtc = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": round(n_cpu / dtc, 3), "unit": "images/s", "cores": O.num_threads(), "kind": "port",
                                    "sample": f"{n_cpu} images of the same batch through oracle/vit_oracle.c (ggml-semantics restatement, OpenMP, NOT ggml itself), {dtc:.1f} s"}
+            mode_same = O.GPU_BF16 if args.dtype == "bf16" else dataclasses.replace(O.REF, quant_act=0) if quant else None
+            got = timed_probs[:n_cpu]
+            par = {"rows": n_cpu, "what": "class probabilities of the TIMED configuration (rows 0..n-1 of the batch the timed steps ran) vs oracle/vit_oracle.c on the same images",
+                   "max_dprob_vs_ref": float(np.abs(got - ref_p).max()), "top1_equal": bool((got.argmax(1) == ref_p.argmax(1)).all()),
+                   "top1_prob_range": [round(float(ref_p.max(1).min()), 3), round(float(ref_p.max(1).max()), 3)]}
+            if mode_same is not None:
+                _, same_p = om.forward(cpu_imgs, mode_same)
+                par["max_dprob_vs_bf16_oracle" if args.dtype == "bf16" else "max_dprob_vs_dequantised_oracle"] = float(np.abs(got - same_p).max())
+            out["parity"] = par
+            oracle_rows = (cpu_imgs, ref_p)
+            assert par["top1_equal"], f"timed configuration disagrees with the oracle on top-1: {par}"
+
+        # ---- secondary measurements, after the timed region and outside `value`
+        if world == 1 and not args.no_extras and args.model == "vit_base_patch16_224" and args.ftype == "f16":
+            extras_t0 = time.perf_counter()
+            # (1) sustained: >= 3 s of back-to-back forwards of the SAME context (the power limiter's averaging window has engaged)
+            n_sus = max(50, int(3.2 / (ms_per_step * 1e-3)))
+            with SmiSampler(local_rank) as smi:
+                rate, ms = quick_rate(ctx, B, imgs, probs, n_sus, warm=0)
+            out["sustained"] = {"value": round(rate, 1), "unit": "images/s", "ms_per_step": round(ms, 4), "steps": n_sus, "seconds": round(n_sus * ms * 1e-3, 2), "rocm_smi": smi.summary()}
+            # (2) the parity mode (fp16 operands: the reference's rounding points) on the same batch
+            if args.dtype == "bf16":
+                c16 = binding.Context(model, device=local_rank, max_batch=B, dtype=binding.F16)
+                p16 = torch.empty_like(probs)
+                rate, ms = quick_rate(c16, B, imgs, p16, max(5, args.steps // 2))
+                f16m = {"value": round(rate, 1), "unit": "images/s", "ms_per_step": round(ms, 4)}
+                if oracle_rows is not None:
+                    g16 = p16[:oracle_rows[1].shape[0]].cpu().numpy()
+                    f16m["max_dprob_vs_ref"] = float(np.abs(g16 - oracle_rows[1]).max()); f16m["top1_equal"] = bool((g16.argmax(1) == oracle_rows[1].argmax(1)).all())
+                out["f16_parity_mode"] = f16m
+                c16.close(); del p16
+            ctx.close()
+            # (3) BASELINE.json configs 5 and 3 as short lines, so that they are driver-observed
+            others = {}
+            try:
+                qpath = pkg.synth.cached_synthetic(args.model, ftype=2, head_scale=8.0)
+                qm = binding.Model(qpath); qc = binding.Context(qm, device=local_rank, max_batch=B, dtype=dt)
+                qp = torch.empty_like(probs)
+                rate, ms = quick_rate(qc, B, imgs, qp, 5)
+                line = {"value": round(rate, 1), "unit": "images/s", "ms_per_step": round(ms, 4), "steps": 5, "weight_bytes_hbm": qc.weight_bytes()}
+                if oracle_rows is not None:       # vs the f16 file's reference probabilities: what 4.5-bit weights cost on this head
+                    line["max_dprob_vs_f16_file_ref"] = float(np.abs(qp[:oracle_rows[1].shape[0]].cpu().numpy() - oracle_rows[1]).max())
+                others[f"{args.model} q4_0 file bs={B} {args.dtype}"] = line
+                qc.close(); qm.close(); del qp
+            except Exception as e:
+                others["q4_0"] = {"error": str(e)}
+            try:
+                lname, lb = "vit_large_patch16_384", 128
+                lpath = pkg.synth.cached_synthetic(lname, head_scale=8.0)
+                lhp = pkg.synth.hparams_for(lname)
+                lm = binding.Model(lpath); lc = binding.Context(lm, device=local_rank, max_batch=lb, dtype=dt)
+                limgs = torch.randn((lb, lhp.img_size, lhp.img_size, 3), device="cuda"); lp = torch.empty((lb, lhp.num_classes), device="cuda")
+                rate, ms = quick_rate(lc, lb, limgs, lp, 5)
+                assert torch.isfinite(lp).all()
+                lg = pkg.synth.gflop_per_image(lhp)
+                others[f"{lname} bs={lb} {args.dtype}"] = {"value": round(rate, 1), "unit": "images/s", "ms_per_step": round(ms, 4), "steps": 5, "gflop_per_image": round(lg, 4),
+                                                            "mfma_roofline_frac_whole_forward": round(rate * lg / 1e3 / PEAK_TFLOPS, 4)}
+                lc.close(); lm.close()
+            except Exception as e:
+                others["vit_large_patch16_384"] = {"error": str(e)}
+            out["other_configs"] = others
+            out["extras_wall_s"] = round(time.perf_counter() - extras_t0, 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

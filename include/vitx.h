@@ -215,6 +215,13 @@ int vitx_op_gemm(int dtype, int epi, const void *d_a, const void *d_w, const voi
  * VITX_ERR_UNSUPPORTED when the chosen kernel cannot tile the shape. */
 int vitx_op_gemm_ex(int dtype, int epi, int kernel, const void *d_a, const void *d_w, const void *d_bias, void *d_out, const void *d_pos,
                     int M, int M_real, int N, int K, int tpi, void *stream);
+/* The residual GEMM with the LayerNorm that follows it computed in its epilogue (what proj + norm2 and fc2 + the next norm1 run as at
+ * large batches): d_x f32 [M][N] += A . W^T + bias in place, d_y (dtype) [M][N] = ((x - mean) / sqrt(var + eps)) * ln_w + ln_b of the
+ * updated rows.  M % 256 == 0, N in {256, 512, 768, 1024}, K % 128 == 0, at least 128 tiles of 256 x 256 (VITX_ERR_UNSUPPORTED otherwise).
+ * test: 0; 1 = every fifth tile behaves as if a peer workgroup had timed out; 3 = and really withholds its statistics (its peers time out
+ * after timeout_us microseconds) -- the fix-up launch must then produce the same bits.  Synchronous.  *fallbacks = tiles left to the fix-up. */
+int vitx_op_gemm_ln(int dtype, const void *d_a, const void *d_w, const void *d_bias, void *d_x, const void *d_ln_w, const void *d_ln_b, void *d_y,
+                    int M, int N, int K, float eps, int test, int timeout_us, int *fallbacks, void *stream);
 /* Block-quantised weights on the device (reference: ggml keeps q4_0 ... q8_0 tensors in block form through compute,
  * vit.cpp:384-414, 645-678).  A context built from a quantised file keeps the blocks in HBM (vitx_ctx_weight_bytes reports the
  * footprint; vitx_ctx_options::quant_on_host expands once on the host instead) and expands them on the device:
@@ -229,6 +236,10 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *d_a, const void *d_qs, const
                     int M, int M_real, int N, int K, void *stream);
 /* Device bytes held by the context's weight matrices (blocks for quantised tensors, 16-bit operands otherwise). */
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c);
+/* Diagnostic: GEMM tiles whose fused LayerNorm was left to the fix-up launch since the context was created (a peer workgroup did not
+ * publish its row statistics in time -- possible when two such GEMMs on the context's two streams hold each other's CUs; results are
+ * the same bits either way).  Synchronises the device.  -1 on error. */
+long long vitx_ctx_ln_fallbacks(vitx_ctx *c);
 /* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
 int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* kernel 0 = automatic, 1 = single-pass kernel (N <= 224, 257-288 or 577-608 tokens only),

@@ -98,6 +98,46 @@ template <> struct AttnExp<__bf16> {
 };
 
 // ------------------------------------------------------------------------------------------------
+// LayerNorm statistics by 256-column tiles (ggml_norm, /root/reference/vit.cpp:808-812, 881-885): the ONE definition both the
+// stand-alone kernel (kernels.hip) and the LayerNorm fused into the residual GEMMs (gemm_pp.hip) follow, operation for operation,
+// so that a row's result does not depend on which of them produced it (batch-size independence of the whole forward).
+//   tile c (columns 256 c ..): the row's 256 values are 64 pieces of 4 consecutive columns; piece id = 16 w + 8 j + k
+//     a(piece)  = (x0 + x1) + (x2 + x3)
+//     s(w, k)   = a(w, 0, k) + a(w, 1, k)
+//     P(w)      = ln_sum8 over k = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7))      -- a butterfly: every k holds the same bits
+//     S_c       = ((P(0) + P(1)) + P(2)) + P(3);   mean_c = S_c / 256
+//     M2_c      = the same tree over (x - mean_c)^2  (two passes inside the tile: no cancellation)
+//   row: ln_combine() merges the tiles in index order (Chan et al.: equal counts): mean = (sum of mean_c) / NT,
+//     M2 = sum of M2_c + 256 * sum of (mean_c - mean)^2, rstd = 1 / sqrt(M2 / D + eps);  y = ((x - mean) * rstd) * w + b.
+// ggml's own order (double accumulation over the whole row) differs from this by f32 rounding only: within one operand ulp of
+// oracle.layernorm (tests/test_gpu_kernels.py, test_gpu_parity_r02.py).
+// ------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+// sum over the 8 lanes that share (lane >> 3); every one of them ends up with the same bits
+__device__ __forceinline__ float ln_sum8(float v) {
+    v = v + dpp_f32<0xB1>(v);       // quad_perm [1, 0, 3, 2]: k ^ 1
+    v = v + dpp_f32<0x4E>(v);       // quad_perm [2, 3, 0, 1]: k ^ 2
+    v = v + dpp_f32<0x141>(v);      // row_half_mirror: the other quad of the 8
+    return v;
+}
+__device__ __forceinline__ float ln_piece_sum(f32x4 x) { return (x[0] + x[1]) + (x[2] + x[3]); }
+__device__ __forceinline__ float ln_piece_sq(f32x4 x, float m) {
+    const float d0 = x[0] - m, d1 = x[1] - m, d2 = x[2] - m, d3 = x[3] - m;
+    return (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+}
+constexpr int LN_MAX_TILES = 4;         // hidden sizes 256 .. 1024 take the tiled definition
+__device__ __forceinline__ void ln_combine(const float (&mc)[LN_MAX_TILES], const float (&m2)[LN_MAX_TILES], int NT, int D, float eps, float &mean, float &rstd) {
+    float sm = mc[0], q = m2[0];
+#pragma unroll
+    for (int c = 1; c < LN_MAX_TILES; ++c) if (c < NT) { sm = sm + mc[c]; q = q + m2[c]; }
+    mean = sm / (float)NT;
+    float dv = mc[0] - mean, w = dv * dv;
+#pragma unroll
+    for (int c = 1; c < LN_MAX_TILES; ++c) if (c < NT) { dv = mc[c] - mean; w = w + dv * dv; }
+    rstd = 1.0f / sqrtf((q + 256.0f * w) / (float)D + eps);
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS tile image shared by the GEMM and attention kernels: rows of 64 elements (128 B = 8 slots of
 // 16 B).  Two rows form one 256-B bank line; the 16 slots of a line are XOR-ed with (line & 15) so a
 // ds_read_b128 lane group (16 rows, same logical slot) touches 16 distinct slots: conflict-free.

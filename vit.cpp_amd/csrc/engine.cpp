@@ -82,13 +82,22 @@ struct vitx_ctx {
     // kernels" at every batch size (batch 1: 1.75 vs 1.06 ms, batch 8: 2.15 vs 1.33 ms), so it is an option, not the default.
     int q4_fused_rows = 0;
     size_t weight_bytes = 0;             // device bytes held by weight matrices (vitx_ctx_weight_bytes)
+    // LayerNorm fused into the residual GEMMs (GemmLn, kernels.h): norm2 rides in proj, the next layer's norm1 in fc2, wherever those GEMMs
+    // run on the wide persistent kernel.  vitx_ctx_options::no_ln_fusion turns it off (every LayerNorm its own launch; same bits).
+    bool ln_fuse = true;
+    unsigned ln_epoch = 0;               // tag of the next fused launch (unique per launch; 0 is never used)
+    unsigned ln_timeout = 20000;         // 200 us of the 100 MHz wall clock before a workgroup leaves its tile to the fix-up launch
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
     // (measured +10 % images/s at batch 256, tools/two_stream_probe.py).  Sub-batches are independent images.
     struct Slice {
         int cap = 0;                 // images this slice can hold
         float *X = nullptr;          // [Mpad][D] f32 residual stream
-        void *U = nullptr;           // [Mpad][D] LN output / attention output
+        void *U = nullptr;           // [Mpad][D] norm1 output / attention output
+        void *U2 = nullptr;          // [Mpad][D] norm2 output (its own buffer: proj reads U while its epilogue writes the normalised rows)
+        unsigned long long *ln_sync = nullptr;   // [Mpad / 256][D / 256][256][2] statistics granules of the fused LayerNorm
+        unsigned *ln_todo = nullptr;             // [ln_blocks] row blocks left to the fix-up launch; [ln_blocks] = the fallback counter
+        int ln_blocks = 0;                       // Mpad / 256 of the slice's capacity
         void *QKV = nullptr;         // [Mpad][3D]
         void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
         void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
@@ -230,12 +239,14 @@ struct ProfScope {
 
 // `fused` != nullptr: W is that q4_0 matrix and the GEMM expands the blocks in its own LDS-fill path (small batches).
 int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
-         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr) {
+         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr, const GemmLn *ln = nullptr) {
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
     a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
+    a.ln = ln;
     double bytes = (double)M_real * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
+    if (ln) bytes += (double)M_real * N * 2;
     ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
     if (fused) {
         a.W = fused->blocks; a.Wscale = fused->scales;
@@ -289,6 +300,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->quant_on_device = !opt.quant_on_host;
     c->q4_fused_rows = opt.q4_fused_rows;
     c->graphs_on = opt.graph != 0;
+    c->ln_fuse = !opt.no_ln_fusion && !opt.graph;        // a captured launch would replay its epoch tag: no fusion under the graph cache
 #ifdef VITX_LAB
     if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);
     if (const char *e = getenv("VITX_SPLIT")) c->split_first = atoi(e);
@@ -338,6 +350,12 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
         const size_t Mpad = (size_t)round_up(sl.cap * c->N, c->tm), Bpad = (size_t)round_up(sl.cap * c->R, c->tm);
         if ((rc = c->dmalloc((void **)&sl.X, Mpad * D * 4, true))) return rc;
         if ((rc = c->dmalloc(&sl.U, Mpad * D * 2, true))) return rc;
+        if ((rc = c->dmalloc(&sl.U2, Mpad * D * 2, true))) return rc;
+        if (D % 256 == 0 && D / 256 <= 4) {
+            if ((rc = c->dmalloc((void **)&sl.ln_sync, (Mpad / 256) * (size_t)(D / 256) * 256 * 2 * sizeof(unsigned long long), true))) return rc;
+            if ((rc = c->dmalloc((void **)&sl.ln_todo, (Mpad / 256 + 1) * sizeof(unsigned), true))) return rc;
+            sl.ln_blocks = (int)(Mpad / 256);
+        }
         if ((rc = c->dmalloc(&sl.QKV, Mpad * 3 * D * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
@@ -430,6 +448,37 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
 #else
     constexpr int skip = 0;
 #endif
+    // LayerNorm fusion: decided per forward (the GEMM shape of this sub-batch must take the wide persistent kernel; never while the caller is
+    // capturing a graph -- the epoch tag of a captured launch would be replayed).  The padded rows M_real .. M of X are then computed and
+    // stored as well (GemmLn): they belong to this slice's scratch, start as zeros and stay finite.
+    bool fuse = false;
+    if (c->ln_fuse && sl.ln_sync) {
+        GemmArgs probe{}; probe.M = M; probe.N = D; probe.N_pad = round_up(D, tn); probe.K = D; probe.lda = D; probe.ldw = D; probe.ldo = D;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusActive; }
+        GemmArgs probe2 = probe; probe2.K = 4 * D; probe2.lda = 4 * D; probe2.ldw = 4 * D;
+        fuse = cs == hipStreamCaptureStatusNone && gemm_ln_fusable(tn_, probe) && gemm_ln_fusable(tn_, probe2);
+    }
+    // residual GEMM (+ the LayerNorm that follows it, fused when `fuse`; otherwise its own launch) -- proj + norm2, fc2 + the next norm1
+    auto resid_gemm_ln = [&](int pc, const void *A, const void *W, const float *bias, int K, const QuantW *fq, const float *lw, const float *lb, void *ln_out) -> int {
+        int rc2;
+        if (fuse && lw && !fq) {
+            GemmLn ln{};
+            ln.w = lw; ln.b = lb; ln.out = ln_out; ln.eps = c->hp.eps; ln.sync = sl.ln_sync; ln.todo = sl.ln_todo; ln.fallbacks = sl.ln_todo + sl.ln_blocks;
+            if (++c->ln_epoch == 0) c->ln_epoch = 1;
+            ln.epoch = c->ln_epoch; ln.timeout = c->ln_timeout;
+            if ((rc2 = gemm(c, tn_, st, pc, EPI_BIAS_RESID, A, W, bias, sl.X, nullptr, M, M, D, round_up(D, tn), K, K, K, D, 0, 4, nullptr, &ln))) return rc2;
+            ProfScope ps(c, st, PC_LAYERNORM, 0, 0);
+            HIP_TRY(launch_layernorm_fixup(dt, sl.X, lw, lb, ln_out, M, D, c->hp.eps, sl.ln_todo, ln.epoch, st));
+            return VITX_OK;
+        }
+        if ((rc2 = gemm(c, tn_, st, pc, EPI_BIAS_RESID, A, W, bias, sl.X, nullptr, M, M_real, D, round_up(D, tn), K, K, K, D, 0, 4, fq))) return rc2;
+        if (lw) {
+            ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
+            if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, lw, lb, ln_out, D, M_real, D, c->hp.eps, st));
+        }
+        return VITX_OK;
+    };
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
         const void *Wl[W_PER_LAYER] = {w.qkv_w, w.proj_w, w.fc1_w, w.fc2_w};
@@ -444,7 +493,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             }
             if (any && (rc = expand(todo, sl.Wq, W_PER_LAYER))) return rc;
         }
-        {   // norm1 (vit.cpp:808-812)
+        if (il == 0) {   // norm1 of the first layer (vit.cpp:808-812); every later norm1 comes out of the previous layer's fc2
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
             if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
@@ -454,15 +503,12 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
             if (!(skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
-        // output projection + residual (vit.cpp:868-873)
-        if ((rc = gemm(c, tn_, st, PC_GEMM_PROJ, EPI_BIAS_RESID, sl.U, Wl[W_PROJ], w.proj_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), D, D, D, D, 0, 4, Fl[W_PROJ]))) return rc;
-        {   // norm2 (vit.cpp:881-885)
-            ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
-            if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln2_w, w.ln2_b, sl.U, D, M_real, D, c->hp.eps, st));
-        }
-        // MLP (vit.cpp:889-900)
-        if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1]))) return rc;
-        if ((rc = gemm(c, tn_, st, PC_GEMM_FC2, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.X, nullptr, M, M_real, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2]))) return rc;
+        // output projection + residual (vit.cpp:868-873), then norm2 (vit.cpp:881-885) -> U2
+        if ((rc = resid_gemm_ln(PC_GEMM_PROJ, sl.U, Wl[W_PROJ], w.proj_b, D, Fl[W_PROJ], w.ln2_w, w.ln2_b, sl.U2))) return rc;
+        // MLP (vit.cpp:889-900), then the NEXT layer's norm1 (vit.cpp:808-812) -> U; the last layer is followed by the cls-row norm instead
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U2, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1]))) return rc;
+        const LayerW *nx = il + 1 < c->L ? &c->layers[il + 1] : nullptr;
+        if ((rc = resid_gemm_ln(PC_GEMM_FC2, sl.Hbuf, Wl[W_FC2], w.fc2_b, 4 * D, Fl[W_FC2], nx ? nx->ln1_w : nullptr, nx ? nx->ln1_b : nullptr, sl.U))) return rc;
         if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D.  ViTSTR (vitstr.cpp:864-895) keeps the first
@@ -504,6 +550,14 @@ static double gemm_round_cost(long rows, int N, int K, int n_cu) {
     if (tiles < 128) return (double)(((rows + 127) / 128 * ntn + n_cu - 1) / n_cu) * t_half;
     return (double)((tiles + n_cu - 1) / n_cu) * t_tile;
 }
+// the LayerNorm-fusing residual GEMMs (proj, fc2) run rounds of gemm_ln_grid() workgroups: whole row blocks per XCD, column tiles of a
+// row block in the same round; + 2 units per tile for the statistics exchange and the normalised store
+static double gemm_round_cost_ln(long rows, int N, int K, int n_cu) {
+    const long ntm = (rows + 255) / 256, ntn = N / 256;
+    const int grid = gemm_ln_grid(n_cu, (int)(ntm * 256), N);
+    const long most = ((ntm + 7) / 8) * ntn, wgx = grid / 8;
+    return (double)((most + wgx - 1) / wgx) * (K / 32.0 * 0.98 + 3.5 + 2.0);
+}
 static void split_batch(const vitx_ctx *c, int n, int ns, int *m) {
     const int base = n / ns, extra = n % ns;
     for (int i = 0; i < ns; ++i) m[i] = base + (i < extra ? 1 : 0);
@@ -511,9 +565,12 @@ static void split_batch(const vitx_ctx *c, int n, int ns, int *m) {
     if (ns != 2) return;
     const int n_cu = c->tune->n_cu;
     const int D = c->D;
+    const bool ln = c->ln_fuse && c->slices[0].ln_sync;
     auto layer = [&](int imgs) {
         const long rows = (long)imgs * c->N;
-        return gemm_round_cost(rows, 3 * D, D, n_cu) + gemm_round_cost(rows, D, D, n_cu) + gemm_round_cost(rows, 4 * D, D, n_cu) + gemm_round_cost(rows, D, 4 * D, n_cu);
+        const bool fl = ln && ((rows + 255) / 256) * (D / 256) >= 128;        // the fused kernel needs the wide path (is_wide, kernels.hip)
+        return gemm_round_cost(rows, 3 * D, D, n_cu) + gemm_round_cost(rows, 4 * D, D, n_cu) +
+               (fl ? gemm_round_cost_ln(rows, D, D, n_cu) + gemm_round_cost_ln(rows, D, 4 * D, n_cu) : gemm_round_cost(rows, D, D, n_cu) + gemm_round_cost(rows, D, 4 * D, n_cu));
     };
     double best = layer(m[0]) + layer(m[1]);
     for (int s1 = std::max(8, n / 4); s1 <= n / 2; ++s1) {
@@ -689,6 +746,39 @@ int vitx_op_gemm(int dtype, int epi, const void *a, const void *w, const void *b
     if (epi < 0 || epi > 3 || N % 64) { set_error("vitx_op_gemm: epi 0..3, N %% 64 == 0"); return VITX_ERR_ARG; }
     return op_gemm_impl(dtype, epi, 0, a, w, bias, out, nullptr, M, M, N, round_up(N, gemm_tile_n()), K, 0, stream);   // W and bias hold N rounded up to 128 rows
 }
+// x[M][N] f32 += A[M][K] . W[N][K]^T + bias, then y[M][N] (dtype) = LayerNorm(x) * ln_w + ln_b computed by the GEMM's own epilogue
+// (GemmLn) + the fix-up launch.  `test`: GemmLn::test (forced time-outs).  Synchronous; *fallbacks = tiles that took the fix-up path.
+int vitx_op_gemm_ln(int dtype, const void *a, const void *w, const void *bias, void *x, const void *ln_w, const void *ln_b, void *y, int M, int N, int K, float eps,
+                    int test, int timeout_us, int *fallbacks, void *stream) {
+    if (!a || !w || !bias || !x || !ln_w || !ln_b || !y || M <= 0 || timeout_us < 0) { set_error("vitx_op_gemm_ln: invalid argument"); return VITX_ERR_ARG; }
+    const Tuning *t0 = tuning_for_device(-1);
+    if (!t0) { set_error("vitx_op_gemm_ln: kernel bring-up failed"); return VITX_ERR_HIP; }
+    GemmArgs g{};
+    g.A = a; g.W = w; g.bias = (const float *)bias; g.out = x; g.M = M; g.M_real = M; g.N = N; g.N_pad = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N;
+    if (!gemm_ln_fusable(*t0, g)) { set_error("vitx_op_gemm_ln: M %d N %d K %d does not take the LayerNorm-fusing kernel (M %% 256, N in {256,512,768,1024}, >= 128 tiles, K %% 128)", M, N, K); return VITX_ERR_UNSUPPORTED; }
+    static unsigned epoch = 0x40000000u;       // its own tag range (the scratch is private to the call anyway)
+    const size_t nb = (size_t)M / 256, sync_bytes = nb * (N / 256) * 256 * 2 * sizeof(unsigned long long);
+    unsigned long long *sync = nullptr; unsigned *todo = nullptr;
+    HIP_TRY(hipMalloc((void **)&sync, sync_bytes));
+    if (hipMalloc((void **)&todo, (nb + 1) * 4) != hipSuccess) { (void)hipFree(sync); return VITX_ERR_NOMEM; }
+    int rc = VITX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GemmLn ln{};
+    ln.w = (const float *)ln_w; ln.b = (const float *)ln_b; ln.out = y; ln.eps = eps; ln.sync = sync; ln.todo = todo; ln.fallbacks = todo + nb;
+    ln.epoch = ++epoch; ln.timeout = (unsigned)timeout_us * 100u; ln.test = test;
+    g.ln = &ln;
+    hipError_t e = hipMemsetAsync(sync, 0, sync_bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(todo, 0, (nb + 1) * 4, st);
+    if (e == hipSuccess) e = launch_gemm(*t0, dtype, EPI_BIAS_RESID, g, st);
+    if (e == hipSuccess) e = launch_layernorm_fixup(dtype, (const float *)x, ln.w, ln.b, y, M, N, eps, todo, ln.epoch, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    unsigned fb = 0;
+    if (e == hipSuccess) e = hipMemcpy(&fb, todo + nb, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("vitx_op_gemm_ln: %s", hipGetErrorString(e)); rc = VITX_ERR_HIP; }
+    if (fallbacks) *fallbacks = (int)fb;
+    (void)hipFree(sync); (void)hipFree(todo);
+    return rc;
+}
 // quantised-weight kernels (quant.hip, gemm_nt_kernel<.., Q4>): blocks in the FILE's byte layout for every type except q4_0, whose
 // nibble plane / scale plane split is done here the way the context does it at upload
 int vitx_op_dequant(int dtype, int qtype, const void *blocks, const void *scales, void *out, int N, int n_pad, int K, void *stream) {
@@ -710,6 +800,18 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *a, const void *qs, const voi
     return VITX_OK;
 }
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c) { return c ? c->weight_bytes : 0; }
+long long vitx_ctx_ln_fallbacks(vitx_ctx *c) {
+    if (!c) return -1;
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    long long total = 0;
+    for (auto &sl : c->slices) {
+        if (!sl.ln_todo) continue;
+        unsigned v = 0;
+        if (hipMemcpy(&v, sl.ln_todo + sl.ln_blocks, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        total += v;
+    }
+    return total;
+}
 
 int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) {
     if (!qkv || !out || n_img <= 0 || kernel < 0) return VITX_ERR_ARG;

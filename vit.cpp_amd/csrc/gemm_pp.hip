@@ -63,11 +63,194 @@ __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "mem
 // whole-row stores of the staged epilogue per wave and tile (epilogue16_staged): the next tile's K loop skips over exactly this many
 template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
 
+// ---- EPI_BIAS_RESID + LayerNorm of the finished rows (GemmLn, kernels.h), for one full 256 x 256 tile of the persistent kernel.
+// Statistics follow device_common.h "LayerNorm statistics by 256-column tiles": this workgroup's tile is tile c = n0 / 256 of its rows;
+// wave column w = the 64-column chunk, accumulator half j and 16-byte piece k = lane & 7 of the staged row layout name the pieces.
+//   passes   the staged f32 epilogue (bias, + residual, whole-line X stores); the final values stay in the accumulator registers
+//   (1)      tile sums: in-lane over j, ln_sum8 over k, the four wave columns through LDS            -> mean_c   [2 barriers]
+//   (2)      centred sums of squares the same way                                                    -> M2_c     [1 barrier]
+//   (3)      one thread per row publishes {mean_c, M2_c} as two 8-byte granules {value, tag = epoch} (ONE sc1 store each: the data
+//            is the flag, cdna_hip_programming.md Guideline 16 R2) and polls the other column tiles' granules of the same rows
+//            (relaxed agent-scope loads, s_sleep, bounded by the wall clock)                                     [1 barrier]
+//   (4)      ln_combine in tile order; every lane normalises the 16 rows x 8 columns it holds and stores them to ln.out  [1 barrier]
+// LDS: the statistics live in the operand ring's half-tile slot A1 of buffer 1 -- last read in the tile's final K-tile, re-staged only
+// in phase 2 of the next tile's first K-tile, and every wave is past the K loop here (the wave rows are aligned around the epilogue).
+// Returns true when exactly pp_epi_stores<EPI_BIAS_RESID>() = 32 stores per lane are still in flight (the caller's counted vmcnt
+// skips them), false when the tile was left to the fix-up (everything drained).
+// In-place safety (proj: A == an earlier LayerNorm's output buffer is NOT this one: the engine alternates two U buffers).
+template <typename T>
+__device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &ln, f32x4 (&acc)[8][4], __amdgpu_buffer_rsrc_t ro, char *smem,
+                                               int voff_in, int soff, int soff8, int tid_in, int m0, int n0, int ntn) {
+    using namespace pp;
+    typedef unsigned long long u64;
+    // Everything per-lane below is derived from OPAQUE copies made here, once per tile: the addresses are invariant across the persistent
+    // tile loop, and hipcc otherwise hoists some 80 of them in front of the K loops -- where the kernel has no register to spare -- and spills them
+    // (a spill is a vector-memory operation: it would also break the counted vmcnt of the K loop).
+    int tid = tid_in, voff = voff_in;
+    asm volatile("" : "+v"(tid), "+v"(voff));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, g4 = lane >> 4, lr = lane >> 3, lk = lane & 7;
+    char *patch = smem + LDS + wave * 4096;
+    char *sb = smem + off_a(1, 1);                            // 16 KiB free during the epilogue (see above)
+    float *part = (float *)sb;                                // [4 wave columns][256 rows]
+    float *cmean = (float *)(sb + 4096);                      // [256] mean of this tile's 256 columns
+    float *stat = (float *)(sb + 5120);                       // [LN_MAX_TILES][256][2] {mean_c, M2_c} of every column tile of these rows
+    float *fin = (float *)(sb + 13312);                       // [256][2] {mean, rstd}
+    int *fail = (int *)(sb + 15360);
+    const int rd_off = lr * 128 + ((lk ^ (lr & 7)) * 16);     // row layout of the patch: row lr + 8 t, 16-byte piece lk
+    const int mb = m0 / BM, ct = n0 / BN;
+    if (tid == 0) *fail = 0;
+    // ---- passes (epilogue16_staged, f32 + residual), keeping the stored values: xv(c, t) = row (c >> 1) * 32 + lr + 8 t, columns (c & 1) * 32 + 4 lk ..
+    // (register budget: the kernel sits at 256.  The bias is therefore added in ROW layout -- 2 x 4 values per lane instead of the 4 x 4 of
+    // the accumulator layout, same (acc + bias) + x order -- and nothing but xv accumulates across the passes.)
+    // xv(c, t) ALIASES the accumulator registers pass c has just consumed: for hipcc the accumulators stay live into the next tile's K loop
+    // (they are re-zeroed under a run-time condition), so a second 128-register array could only be spilled
+#define xv(c, t) acc[2 * ((c) >> 1) + ((t) >> 1)][2 * ((c) & 1) + ((t) & 1)]
+    {
+        f32x4 br[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) br[j] = *(const f32x4 *)(patch + j * 128 + lk * 16);       // bias of columns j * 32 + 4 lk .. of the wave's 64 (LDS-DMA'd during the K loop)
+        pp_lds_fence();
+        u32x4 res[2][4];
+        auto load_res = [&](int c, u32x4 (&dst)[4]) {
+            const int i = c >> 1, j = c & 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+        };
+        load_res(0, res[0]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int i = c >> 1, j = c & 1;
+            if (c + 1 < 8) load_res(c + 1, res[(c + 1) & 1]);
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {
+                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu) *(f32x4 *)(patch + prow * 128 + (((4 * uu + g4) * 16) ^ x16)) = acc[2 * i + tp][2 * j + uu];
+            }
+            pp_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xv(c, t) = *(const f32x4 *)(patch + t * 1024 + rd_off);
+            pp_lds_fence();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xv(c, t) = (xv(c, t) + br[j]) + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
+                pp_store_b128(__builtin_bit_cast(u32x4, xv(c, t)), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
+            }
+        }
+    }
+    // LayerNorm weight / bias of this lane's 2 x 4 columns: in flight under the statistics
+    f32x4 gw[2], gb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { gw[j] = *(const f32x4 *)(ln.w + n0 + wc * 64 + j * 32 + lk * 4); gb[j] = *(const f32x4 *)(ln.b + n0 + wc * 64 + j * 32 + lk * 4); }
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // ---- (1) tile sums -> mean_c
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float p = ln_sum8(ln_piece_sum(xv(2 * i, t)) + ln_piece_sum(xv(2 * i + 1, t)));
+            if (lk == 0) part[wc * 256 + wr * 128 + i * 32 + t * 8 + lr] = p;
+            __builtin_amdgcn_sched_barrier(0);      // one row at a time: hipcc otherwise interleaves all 16 and spills the tile it is reducing
+        }
+    lds_barrier();
+    if (tid < 256) cmean[tid] = (((part[tid] + part[256 + tid]) + part[512 + tid]) + part[768 + tid]) * (1.0f / 256.0f);
+    lds_barrier();
+    // ---- (2) centred sums of squares -> M2_c
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float mc = cmean[wr * 128 + i * 32 + t * 8 + lr];
+            const float q = ln_sum8(ln_piece_sq(xv(2 * i, t), mc) + ln_piece_sq(xv(2 * i + 1, t), mc));
+            if (lk == 0) part[wc * 256 + wr * 128 + i * 32 + t * 8 + lr] = q;        // every wave read cmean, not part, since the last barrier
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    lds_barrier();
+    // ---- (3) publish this tile's statistics, collect the peers'
+    const unsigned epoch = ln.epoch;
+    const bool fake = (ln.test & 1) && ((mb * ntn + ct) % 5 == 0);          // parity tests: this tile behaves as if a peer had timed out
+    {
+        const int r = tid & 255;
+        if (tid < 256) {
+            const float m = cmean[r], q2 = ((part[r] + part[256 + r]) + part[512 + r]) + part[768 + r];
+            stat[(ct * 256 + r) * 2] = m; stat[(ct * 256 + r) * 2 + 1] = q2;
+            if (!(fake && (ln.test & 2))) {
+                u64 *gp = ln.sync + ((size_t)(mb * ntn + ct) * 256 + r) * 2;
+                __hip_atomic_store(gp, ((u64)epoch << 32) | __builtin_bit_cast(unsigned, m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gp + 1, ((u64)epoch << 32) | __builtin_bit_cast(unsigned, q2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        for (int pi = tid >> 8; pi < ntn - 1; pi += 2) {                   // the two halves of the workgroup poll different peers
+            const int c2 = pi < ct ? pi : pi + 1;
+            const u64 *gp = ln.sync + ((size_t)(mb * ntn + c2) * 256 + r) * 2;
+            const long long t_start = wall_clock64();
+            bool ok = false;
+            for (;;) {
+                const u64 a = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(a >> 32) == epoch && (unsigned)(b >> 32) == epoch) {
+                    stat[(c2 * 256 + r) * 2] = __builtin_bit_cast(float, (unsigned)a); stat[(c2 * 256 + r) * 2 + 1] = __builtin_bit_cast(float, (unsigned)b);
+                    ok = true; break;
+                }
+                if (wall_clock64() - t_start > (long long)ln.timeout) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!ok) *fail = 1;
+        }
+        if (fake && tid == 0) *fail = 1;
+    }
+    lds_barrier();
+    if (*fail) {           // uniform: leave the row block to launch_layernorm_fixup (it recomputes every tile of the block from X: same bits)
+        if (tid == 0) {
+            __hip_atomic_store(ln.todo + mb, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ln.fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        lds_barrier();     // `fail` and the statistics are re-used by the next tile: nobody may still be reading them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return false;
+    }
+    // ---- (4) whole-row statistics, normalise this tile from registers
+    if (tid < 256) {
+        float m_[LN_MAX_TILES], q_[LN_MAX_TILES];
+#pragma unroll
+        for (int c = 0; c < LN_MAX_TILES; ++c) { m_[c] = c < ntn ? stat[(c * 256 + tid) * 2] : 0.0f; q_[c] = c < ntn ? stat[(c * 256 + tid) * 2 + 1] : 0.0f; }
+        float mean, rstd;
+        ln_combine(m_, q_, ntn, g.N, ln.eps, mean, rstd);
+        fin[tid * 2] = mean; fin[tid * 2 + 1] = rstd;
+    }
+    lds_barrier();
+    {
+        const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(ln.out, 0, (int)0xffffffffu, 0x00020000);
+        // ln.out is [M][N] of T with the GEMM's row length: the X offsets halve (f32 -> 16 bit)
+        const int uoff = voff >> 1, usoff = soff >> 1, usoff8 = soff8 >> 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x2 mr = *(const f32x2 *)(fin + (wr * 128 + i * 32 + t * 8 + lr) * 2);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float v = (xv(2 * i + j, t)[e] - mr[0]) * mr[1]; v = v * gw[j][e]; o[e] = v + gb[j][e]; }
+                    const typename Pair<T>::v2 lo = round_pair<T>(o[0], o[1]), hi = round_pair<T>(o[2], o[3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, ru, uoff + j * 64, usoff + (i * 4 + t) * usoff8, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+    lds_barrier();         // the statistics area (and `fail`) is re-used by the next tile, and the ring slot is re-staged soon after
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // at most the 32 U stores stay in flight (X stores of lanes that did not poll included)
+    return true;
+#undef xv
+}
+
 // FLAGS: 0 in the product.  Ablation builds exist only under -DVITX_LAB (tools/gemm_lab): 1 = no s_setprio around the MFMAs,
 // 4 = no LDS-DMA in the loop, 8 = no fragment reads, 16 = no MFMAs, 32 = s_memtime stamp after every barrier of K-tiles 4..7 of the first
 // tile (written to g.pos as [block][wave][64] u32), 512 = direct (unstaged) epilogue, 2048 = no epilogue at all.
-template <typename T, int EPI, int FLAGS>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR))) void gemm_pp_kernel(GemmArgs g) {
+// LNF: EPI_BIAS_RESID with the LayerNorm of the output rows computed in the epilogue (GemmLn, kernels.h; pp_epilogue_ln below).
+template <typename T, int EPI, int FLAGS, bool LNF = false>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR))) void gemm_pp_kernel(GemmArgs g, GemmLn ln) {
     using namespace pp;
     typedef typename Elem<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,21 +259,39 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;            // wave row (= ping-pong group) / wave column
 
-    // ---- tile walk: virtual id v keeps v % 8 == bid % 8 (same XCD), then the XCD-contiguous GROUP_M raster
+    // ---- tile walk: virtual id v keeps v % 8 == bid % 8 (same XCD), then the XCD-contiguous GROUP_M raster.
+    // LNF: an XCD owns whole ROW BLOCKS and walks them column-fastest, and the launcher makes the workgroups per XCD a multiple of
+    // the column tiles: the ntn tiles of a row block then always run in the SAME round on ntn neighbouring workgroups of one XCD --
+    // the peers the LayerNorm epilogue exchanges row statistics with.
     const int ntm = g.M / BM, ntn = g.N_pad / BN, ntiles = ntm * ntn;
     const int nblk = gridDim.x, bid = blockIdx.x;
-    const int my_tiles = (ntiles - bid + nblk - 1) / nblk;
-    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = bid & 7;
-    const int lid_base = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8);
+    const int xcd = bid & 7;
+    int my_tiles_, lid_base_;
+    if constexpr (LNF) {
+        const int qb = ntm >> 3, rb = ntm & 7;
+        const int rows_x = qb + (xcd < rb ? 1 : 0), wgx = nblk >> 3, j = bid >> 3;
+        lid_base_ = (xcd * qb + min(xcd, rb)) * ntn;                   // first tile of this XCD in (row block, column tile) order
+        my_tiles_ = j < rows_x * ntn ? (rows_x * ntn - j + wgx - 1) / wgx : 0;
+    } else {
+        const int q8 = ntiles >> 3, r8 = ntiles & 7;
+        lid_base_ = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8);
+        my_tiles_ = (ntiles - bid + nblk - 1) / nblk;
+    }
+    const int my_tiles = my_tiles_, lid_base = lid_base_;
     const int group_m = g.group_m > 0 ? g.group_m : GROUP_M;
     auto tile_origin = [&](int round, int &m0, int &n0) {
         const int v = bid + round * nblk;
         const int lid = lid_base + (v >> 3);
-        const int per_group = group_m * ntn;
-        const int grp = lid / per_group, within = lid - grp * per_group;
-        const int gm = min(group_m, ntm - grp * group_m);
-        const int tn = within / gm;
-        m0 = (grp * group_m + (within - tn * gm)) * BM; n0 = tn * BN;
+        if constexpr (LNF) {
+            const int mb = lid / ntn;
+            m0 = mb * BM; n0 = (lid - mb * ntn) * BN;
+        } else {
+            const int per_group = group_m * ntn;
+            const int grp = lid / per_group, within = lid - grp * per_group;
+            const int gm = min(group_m, ntm - grp * group_m);
+            const int tn = within / gm;
+            m0 = (grp * group_m + (within - tn * gm)) * BM; n0 = tn * BN;
+        }
     };
     if (my_tiles <= 0) return;
 
@@ -248,7 +449,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             if (round == 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(fa[ii][ks])); asm volatile("" : "+v"(fb[ii][ks])); } }
         }
         if constexpr ((FLAGS & 16) != 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" :: "v"(fa[ii][ks]), "v"(fb[ii][ks])); } }
-        const bool full = (m0 + BM <= g.M_real) && (n0 + BN <= g.N);
+        const bool full = LNF || ((m0 + BM <= g.M_real) && (n0 + BN <= g.N));       // LNF: the padded rows are computed and stored too (GemmLn)
         // The second wave row runs one barrier behind, so its last K-loop barrier would only be released by the first row's first
         // barrier of the NEXT tile -- i.e. after the first row's epilogue, and the two rows' epilogues would run one after the other.
         // Aligning the rows here (and restoring the offset after the epilogue) lets both epilogues run at the same time: forward
@@ -266,8 +467,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             for (int u = 0; u < 4; ++u) bq[u] = *(const f32x4 *)(smem + LDS + wave * 4096 + u * 64 + g4 * 16);
             // readfirstlane: the tile origin comes out of an integer division done on the VALU; without it hipcc wraps every
             // buffer op in a waterfall loop over the (uniform) SGPR offset
-            epilogue16_staged<T, EPI, 4>(acc16, bq, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
-            relaxed = true;
+            if constexpr (LNF) relaxed = pp_epilogue_ln<T>(g, ln, acc16, rsrcO, smem, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, tid, m0, n0, ntn);
+            else {
+                epilogue16_staged<T, EPI, 4>(acc16, bq, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
+                relaxed = true;
+            }
         } else {
             const int row0 = m0 + wr * 128 + l15, ncol = n0 + wc * 64;
             if (full) epilogue16<T, EPI, 8, 4, true>(g, acc16, row0, ncol + 4 * g4);
@@ -298,7 +502,28 @@ static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream
     int cap = n_cu & ~7;                             // the tile walk keeps a workgroup on one XCD: grid is a multiple of 8
     if (cap <= 0) cap = 256;
     const int grid = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI, FLAGS>), dim3(grid), dim3(512), pp::LDS_ALL, stream, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI, FLAGS>), dim3(grid), dim3(512), pp::LDS_ALL, stream, a, GemmLn{});
+    return hipGetLastError();
+}
+// Persistent grid of the LayerNorm-fusing GEMM: 8 XCDs x wgx workgroups, wgx a multiple of the ntn column tiles (so the tiles of a row
+// block share a round) and balanced over the rounds the busiest XCD needs.
+int gemm_pp_ln_grid(int n_cu, int M, int N) {
+    const int ntm = M / pp::BM, ntn = N / pp::BN;
+    int per_xcd = (n_cu > 0 ? n_cu : 256) / 8;
+    if (per_xcd < ntn) per_xcd = ntn;
+    const int cap = per_xcd / ntn * ntn;
+    const int most = ((ntm + 7) / 8) * ntn;                         // tiles of the XCD with the most row blocks
+    const int rounds = (most + cap - 1) / cap;
+    int wgx = ((most + rounds - 1) / rounds + ntn - 1) / ntn * ntn;
+    if (wgx > cap) wgx = cap;
+    return 8 * wgx;
+}
+template <typename T>
+static hipError_t launch_pp_ln(const GemmArgs &a, int n_cu, hipStream_t stream, bool prepare) {
+    if (prepare) return hipFuncSetAttribute((const void *)gemm_pp_kernel<T, EPI_BIAS_RESID, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pp::LDS_ALL);
+    const GemmLn &ln = *a.ln;
+    if (!ln.w || !ln.b || !ln.out || !ln.sync || !ln.todo || !ln.fallbacks || !ln.epoch || a.N != a.N_pad || a.N != a.ldo || a.N / pp::BN > LN_MAX_TILES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI_BIAS_RESID, 0, true>), dim3(gemm_pp_ln_grid(n_cu, a.M, a.N)), dim3(512), pp::LDS_ALL, stream, a, ln);
     return hipGetLastError();
 }
 template <typename T>
@@ -321,6 +546,11 @@ static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t 
 #else
     if (flags) return hipErrorInvalidValue;
 #endif
+    if (a.ln || (prepare && epi == EPI_BIAS_RESID)) {      // bring-up prepares both builds of the residual epilogue
+        if (epi != EPI_BIAS_RESID) return hipErrorInvalidValue;
+        const hipError_t e = launch_pp_ln<T>(a, n_cu, stream, prepare);
+        if (!prepare || e != hipSuccess) return e;
+    }
     switch (epi) {
     case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 0>(a, n_cu, stream, prepare);
     case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 0>(a, n_cu, stream, prepare);

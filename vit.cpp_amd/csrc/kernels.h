@@ -31,6 +31,28 @@ struct GemmArgs {
     // scales [N_pad][K/32]; both planes are the file's block_q4_0 fields re-laid out, 4.5 bits per weight
     const uint16_t *Wscale;
     int group_m;  // ping-pong kernel: m-tiles per raster group (0 = the default, 8)
+    // LayerNorm of the output rows fused into an EPI_BIAS_RESID GEMM on the ping-pong kernel (gemm_ln_fusable()): `ln` != nullptr.
+    const struct GemmLn *ln;
+};
+
+// The LayerNorm that follows a residual GEMM (vit.cpp:881-885 after proj, :808-812 of the next layer after fc2), computed by the
+// GEMM's own epilogue: every workgroup reduces its 256-column tile's per-row statistics from the accumulators, publishes them as
+// data-tagged 8-byte granules, reads the statistics of the row block's other column tiles from its raster-adjacent peers (same
+// round, same XCD), and normalises ITS OWN tile from registers into `out`: X is not re-read, no extra launch, no single-CU tail.
+// All M (padded) rows are computed and stored: the buffers are padded to the row tile, pad rows stay finite and are never read
+// for real rows.  A peer that does not answer within `timeout` (two such GEMMs on two streams can each hold CUs the other's
+// workgroups wait for) makes the workgroup skip its tile and set todo[row block] = epoch; launch_layernorm_fixup() then
+// normalises exactly those row blocks from X with the stand-alone arithmetic -- the same bits (device_common.h "LayerNorm statistics").
+struct GemmLn {
+    const float *w, *b;           // [N]
+    void *out;                    // [M][N] operand type
+    float eps;
+    unsigned long long *sync;     // [M / 256][N / 256][256][2] granules {value bits, tag = epoch}, zeroed once
+    unsigned *todo;               // [M / 256], zeroed once
+    unsigned *fallbacks;          // [1] diagnostic counter: tiles that took the fix-up path
+    unsigned epoch;               // unique per launch within the process, never 0 (frozen under graph replay: callers do not fuse while capturing)
+    unsigned timeout;             // ticks of the 100 MHz wall clock
+    int test;                     // parity tests only: 1 = every 5th tile pretends a time-out, 3 = and does not publish (its peers really time out)
 };
 
 // ---- block-quantised weights resident in HBM (quant.hip) -------------------------------------------
@@ -59,7 +81,6 @@ struct Tuning {
     int gemm_split = 0;      // 1: tail rows of a partial round re-tiled 128x256 in a second launch
     int gemm_balance = 1;    // 0: one workgroup per CU even when the last round of tiles is partial
     int group_m = 0;         // raster group height of the ping-pong kernel (0 = its default)
-    int ln_fuse = 1;         // 0: LayerNorm always as its own kernel (never fused into the proj / fc2 GEMMs)
     int pp_flags = 0;        // ablation build of the ping-pong kernel (exists under VITX_LAB only)
     int gemm_dbg = 0;        // ablation bits of the ring kernel (honoured under VITX_LAB only)
     int attn_kernel = ATTN_AUTO;
@@ -70,6 +91,13 @@ struct Tuning {
 const Tuning *tuning_for_device(int device);
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream);
+// true when launch_gemm runs this EPI_BIAS_RESID GEMM on the ping-pong kernel in one launch with whole rows (N == N_pad == ldo,
+// N / 256 <= 4 column tiles), so that GemmArgs::ln may be set; the caller then launches launch_layernorm_fixup instead of launch_layernorm
+bool gemm_ln_fusable(const Tuning &t, const GemmArgs &a);
+// persistent grid of that GEMM (for the sub-batch cost model): workgroups per XCD are a multiple of the column tiles
+int gemm_ln_grid(int n_cu, int M, int N);
+// normalises the row blocks a fused GEMM left behind (todo[rb] == epoch) from x; a few microseconds when there are none
+hipError_t launch_layernorm_fixup(int dtype, const float *x, const float *w, const float *b, void *y, int M, int D, float eps, const unsigned *todo, unsigned epoch, hipStream_t stream);
 int gemm_tile_m();   // M granularity the GEMM needs (buffer row padding)
 int gemm_tile_n();
 

@@ -194,14 +194,22 @@ static bool is_wide(const GemmArgs &a) {
     const long t256 = (long)(a.M / 256) * (a.N_pad / 256);
     return a.M % 256 == 0 && a.N_pad % 256 == 0 && t256 >= 128 && (gemm_pp_supports(a) || gemm_ring_supports(a, 445));
 }
+int gemm_pp_ln_grid(int n_cu, int M, int N);      // gemm_pp.hip
+int gemm_ln_grid(int n_cu, int M, int N) { return gemm_pp_ln_grid(n_cu, M, N); }
+bool gemm_ln_fusable(const Tuning &t, const GemmArgs &a) {
+    return t.gemm_cfg < 0 && !t.gemm_split && !t.pp_flags && a.M > 0 && is_wide(a) && gemm_pp_supports(a) && a.N == a.ldo && a.N == a.N_pad && a.N % 256 == 0 &&
+           a.N / 256 <= LN_MAX_TILES && (size_t)a.M * a.ldo * 4 < 0xf0000000u;
+}
 static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a0, hipStream_t stream) {
     GemmArgs a = a0; a.group_m = t.group_m;
+    if (a.ln) return (epi == EPI_BIAS_RESID && gemm_ln_fusable(t, a)) ? launch_gemm_pp(dtype, epi, a, t.n_cu, stream, 0) : hipErrorInvalidValue;
     if (gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(a), stream);
 }
 
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
+    if (a.ln && !gemm_ln_fusable(t, a)) return hipErrorInvalidValue;      // the caller asks gemm_ln_fusable first
     int cfg = t.gemm_cfg;
     if (cfg == 1) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     if (cfg > 1) return gemm_ring_supports(a, cfg) ? launch_gemm_ring(t, dtype, epi, a, cfg, stream) : hipErrorInvalidValue;
@@ -292,7 +300,42 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_i
 // LayerNorm (ggml_norm + ggml_mul + ggml_add_inplace, vit.cpp:808-812, 881-885, 915-919):
 // mean, then biased variance of (x-mean), y = ((x-mean) * 1/sqrt(var+eps)) * w + b, rounded to the
 // operand type of the GEMM that consumes it.  One wave per row, row kept in registers.
+// Hidden sizes that are 1..4 tiles of 256 columns (256, 512, 768, 1024: every model the wide GEMMs run) take the TILED statistics
+// of device_common.h, the definition the LayerNorm fused into the residual GEMMs (gemm_pp.hip) follows too: a row gets the same
+// bits whichever of the two produced it.  Lane l of the wave holds piece l of each tile (w = l >> 4, j = (l >> 3) & 1, k = l & 7):
+// one fully coalesced 1 KiB load per tile.
 // ------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+__device__ __forceinline__ void ln_row_tiled(const float *__restrict__ xr, const float *__restrict__ w, const float *__restrict__ b, T *__restrict__ yr, float eps, int lane) {
+    f32x4 v[NT];
+    float mc[LN_MAX_TILES] = {0.0f, 0.0f, 0.0f, 0.0f}, m2[LN_MAX_TILES] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NT; ++c) v[c] = *(const f32x4 *)(xr + c * 256 + lane * 4);
+    auto tile_total = [&](float a) {       // a = this lane's piece value -> S_c (uniform)
+        const float s = a + __shfl_xor(a, 8);                      // s(w, k) = a(w, 0, k) + a(w, 1, k)
+        const float p = ln_sum8(s);                                // P(w), the same bits in the 16 lanes of wave column w
+        const float p0 = __shfl(p, 0), p1 = __shfl(p, 16), p2 = __shfl(p, 32), p3 = __shfl(p, 48);
+        return ((p0 + p1) + p2) + p3;
+    };
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        mc[c] = tile_total(ln_piece_sum(v[c])) * (1.0f / 256.0f);
+        m2[c] = tile_total(ln_piece_sq(v[c], mc[c]));
+    }
+    float mean, rstd;
+    ln_combine(mc, m2, NT, NT * 256, eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int idx = c * 256 + lane * 4;
+        const f32x4 ww = *(const f32x4 *)(w + idx), bb = *(const f32x4 *)(b + idx);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float t = (v[c][e] - mean) * rstd; t = t * ww[e]; o[e] = t + bb[e]; }
+        const typename Pair<T>::v2 lo = round_pair<T>(o[0], o[1]), hi = round_pair<T>(o[2], o[3]);
+        *(typename Elem<T>::v4 *)(yr + idx) = typename Elem<T>::v4{lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+
 template <typename T, int VEC, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ w, const float *__restrict__ b,
                                                         T *__restrict__ y, long ldy, int M, float eps, int group, long gstride) {
@@ -303,6 +346,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     // input row: group == 1 -> row * ldx; otherwise rows come in groups (row / group) * gstride + (row % group) * ldx
     // (the first `group` tokens of every image: the ViTSTR head, vitstr.cpp:864-883)
     const float *xr = group == 1 ? x + (size_t)row * ldx : x + (size_t)(row / group) * gstride + (size_t)(row % group) * ldx;
+    T *yr = y + (size_t)row * ldy;
+    if constexpr (VEC == 4 && NV <= LN_MAX_TILES) { ln_row_tiled<T, NV>(xr, w, b, yr, eps, lane); return; }
     float v[NV][VEC];
     float sum = 0.0f;
 #pragma unroll
@@ -325,7 +370,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o);
     const float scale = 1.0f / sqrtf(sum2 / (float)D + eps);
-    T *yr = y + (size_t)row * ldy;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = (i * 64 + lane) * VEC;
@@ -338,6 +382,34 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             for (int j = 0; j < VEC; ++j) yr[idx + j] = o[j];
         }
     }
+}
+
+// Row blocks a LayerNorm-fusing GEMM left behind (GemmLn: todo[rb] == epoch): 64 workgroups, every wave takes one row of each such
+// block -- no single-CU tail.  With nothing to do (the normal case) a workgroup reads the flags and exits.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void layernorm_fixup_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, T *__restrict__ y,
+                                                              int n_blocks, float eps, const unsigned *__restrict__ todo, unsigned epoch) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+    for (int rb = 0; rb < n_blocks; ++rb) {
+        if (__builtin_nontemporal_load(todo + rb) != epoch) continue;
+        for (int r = wv; r < 256; r += nwv) {
+            const size_t row = (size_t)rb * 256 + r;
+            ln_row_tiled<T, NT>(x + row * (NT * 256), w, b, y + row * (NT * 256), eps, lane);
+        }
+    }
+}
+hipError_t launch_layernorm_fixup(int dtype, const float *x, const float *w, const float *b, void *y, int M, int D, float eps, const unsigned *todo, unsigned epoch, hipStream_t stream) {
+    if (M % 256 || D % 256 || D / 256 < 1 || D / 256 > LN_MAX_TILES) return hipErrorInvalidValue;
+    const dim3 grid(64), blk(256);
+    const int nb = M / 256;
+#define VITX_FIX_CASE(NT)                                                                                   \
+    case NT:                                                                                                \
+        if (dtype == DT_F16) hipLaunchKernelGGL((layernorm_fixup_kernel<_Float16, NT>), grid, blk, 0, stream, x, w, b, (_Float16 *)y, nb, eps, todo, epoch); \
+        else hipLaunchKernelGGL((layernorm_fixup_kernel<__bf16, NT>), grid, blk, 0, stream, x, w, b, (__bf16 *)y, nb, eps, todo, epoch);                    \
+        break;
+    switch (D / 256) { VITX_FIX_CASE(1) VITX_FIX_CASE(2) VITX_FIX_CASE(3) VITX_FIX_CASE(4) default: return hipErrorInvalidValue; }
+#undef VITX_FIX_CASE
+    return hipGetLastError();
 }
 
 template <typename T>
