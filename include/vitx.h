@@ -159,15 +159,29 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs_hwc, int n, void *d_prob
 int vitx_ctx_synchronize(vitx_ctx *c);
 
 /* ---- several GPUs in one process (north_star: batch shards + one RCCL gather) -- */
-/* One context (replicated weights) and one host thread per listed device; vitx_group_forward cuts the n host images into
- * contiguous shards (the first n % n_devices devices take one extra image), runs them concurrently and all-gathers the
- * [n_local][num_classes] probabilities with ONE ncclAllGather over RCCL; `probs` receives all n rows in image order.
- * The reference has no counterpart (single image, single device: vit.cpp:747). */
+/* One context (replicated weights) and one PERSISTENT host thread per listed device (created here, parked between calls).  Images are
+ * cut into contiguous shards, run concurrently, and the results are all-gathered with ONE ncclAllGather over RCCL.
+ * The reference has no counterpart (single image, single device: vit.cpp:747).
+ *   vitx_group_out_floats     floats per image in `probs`: num_classes, or 25 * num_classes for a ViTSTR file
+ *   vitx_group_forward        n host images (f32 HWC, as vit_image_preprocess emits; ViTSTR: one grey plane each); the first n % n_devices
+ *                             devices take one extra image; `probs` receives n x out_floats in image order
+ *   vitx_group_forward_device the shards are ALREADY on their devices: d_imgs[r] = n_local[r] preprocessed images on devices[r]
+ *                             (0 <= n_local[r] <= max_batch_per_device; NULL allowed where n_local[r] == 0).  Nothing crosses PCIe.
+ *                             Afterwards EVERY device holds the gathered result of all shards -- vitx_group_result(g, r) is device r's
+ *                             copy, vitx_group_result_rows() = n_max = the largest shard:
+ *                               topk == 0: [n_devices][n_max][out_floats] f32 probabilities (rows beyond a shard's n_local are zero)
+ *                               topk  > 0: [n_devices][n_max][rows_per_image][topk] pairs {f32 probability, i32 class}, descending,
+ *                                          ties by the lower class (topk <= 16): 8 k bytes per row on the links instead of 4 num_classes
+ *                             Synchronous (returns when every device's stream has finished). */
 typedef struct vitx_group vitx_group;
 int vitx_group_create(const vitx_model *m, const int *devices, int n_devices, int max_batch_per_device, int dtype, vitx_group **out);
 void vitx_group_free(vitx_group *g);
 int vitx_group_num_devices(const vitx_group *g);
+int vitx_group_out_floats(const vitx_group *g);
 int vitx_group_forward(vitx_group *g, const float *imgs_hwc, int n, float *probs);
+int vitx_group_forward_device(vitx_group *g, const void *const *d_imgs, const int *n_local, int topk);
+const void *vitx_group_result(const vitx_group *g, int device_index);
+int vitx_group_result_rows(const vitx_group *g);
 
 /* Sorted top-k of one probability row (vit.cpp:1043-1057: descending by prob). */
 int vitx_topk(const float *probs, int num_classes, int k, int32_t *out_idx, float *out_prob);

@@ -67,3 +67,36 @@ def test_shard_bounds_cover_and_balance(pkg):
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         pkg.dist.shard_bounds(4, 2, 2)
+
+
+@pytest.mark.parametrize("world", [8, 2])
+def test_bench_plumbing_under_torchrun(world):
+    """bench.py exactly as the driver launches it for the scaling run -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with the engine stubbed (--stub-engine: gloo, a
+    stand-in forward that encodes the rank), so that a rank / port / barrier / gather-order bug cannot be the first thing an 8-GPU node
+    finds.  Checked: one JSON line from rank 0 only, whole-job aggregate value over all N ranks, every rank's block of the gathered
+    tensor is THAT rank's (asserted inside bench.py), and the line is stamped invalid (it is not a measurement)."""
+    import json
+    import subprocess
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VITX_")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--stub-engine", "--model", "vit_tiny_patch16_224", "--batch", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["global_batch"] == 4 * world
+    assert abs(d["value"] - 4 * world * 3 / (d["ms_per_step"] * 3e-3)) <= 0.02 * d["value"]          # whole-job aggregate, not per rank
+    assert "stub" in d["invalid"]
+
+
+def test_bench_refuses_development_overrides():
+    """A VITX_* variable (VITX_LIB would load another library, the laboratory build honours VITX_SKIP ...) makes bench.py refuse to
+    measure -- before it touches torch or the GPU."""
+    import subprocess
+    env = dict(os.environ, VITX_SKIP="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "development overrides" in (r.stderr + r.stdout)

@@ -195,3 +195,39 @@ def test_hf_converter_round_trip(pkg, oracle, binding, tmp_path):
     lg, _ = oracle.OracleModel(path).forward(imgs, oracle.IDEAL)
     # the patch kernel is stored in fp16 (vit.cpp:515 requires it): that rounding is the only parameter difference
     assert np.abs(lg - hf).max() <= 2e-3, np.abs(lg - hf).max()
+
+
+def test_timm_state_dict_converter(pkg, binding, tmp_path):
+    """vit.cpp_amd/convert.py --timm-state-dict: a torch-saved timm VisionTransformer state_dict needs no `timm` import -- its names ARE
+    the file format's (the reference writes `timm_model.state_dict()` verbatim, convert-pth-to-ggml.py:121-133).  The hyper-parameters are
+    recovered from the tensor shapes; the written file must be byte-identical to the one written from the same tensors with known
+    hparams, `norm_pre.*` is skipped as the reference does (:117-120), a ViTSTR checkpoint's "module.vitstr." prefix is dropped and its
+    one-channel patch kernel brings the character set as labels, and variants with tensors the format has no slot for are refused."""
+    torch = pytest.importorskip("torch")
+    name = "vit_micro_patch16_64"
+    hp = pkg.synth.hparams_for(name)
+    w = pkg.synth.make_weights(hp, seed=5, head_scale=4.0)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in w.items()}
+    sd["norm_pre.weight"] = torch.ones(hp.hidden_size); sd["norm_pre.bias"] = torch.zeros(hp.hidden_size)
+    pth = str(tmp_path / "m.pth"); torch.save(sd, pth)
+    out = str(tmp_path / "timm.gguf"); want = str(tmp_path / "want.gguf")
+    assert pkg.convert.main(["--timm-state-dict", pth, out, "--ftype", "1"]) == 0
+    pkg.ggml_file.write_model(want, hp, w, id2label=None, ftype=1)
+    pm = binding.Model(out)
+    h = pm.hparams
+    assert (h.hidden_size, h.num_hidden_layers, h.num_attention_heads, h.num_classes, h.patch_size, h.img_size) == (128, 2, 2, 10, 16, 64)
+    assert open(out, "rb").read() == open(want, "rb").read()
+    # ViTSTR checkpoint naming + one input channel
+    vname = "vitstr_micro_patch16_64"
+    vhp = pkg.synth.hparams_for(vname)
+    vw = pkg.synth.make_weights(vhp, seed=6, head_scale=4.0, in_chans=1)
+    torch.save({"module.vitstr." + k: torch.from_numpy(v.copy()) for k, v in vw.items()}, pth)
+    assert pkg.convert.main(["--timm-state-dict", pth, out]) == 0
+    vm = binding.Model(out)
+    assert vm.in_channels == 1 and vm.seq_len == 25 and vm.label(1) == "[s]"
+    # unsupported timm variants are named, not silently mis-written
+    bad = dict(sd); bad["blocks.0.ls1.gamma"] = torch.ones(hp.hidden_size)
+    with pytest.raises(ValueError, match="ls1"):
+        pkg.convert.convert_timm_state_dict(bad, out)
+    with pytest.raises(ValueError, match="missing"):
+        pkg.convert.convert_timm_state_dict({k: v for k, v in sd.items() if k != "head.bias"}, out)

@@ -369,3 +369,42 @@ def test_cpp_example_main_runs_like_the_reference_cli(pkg, binding, oracle, torc
     for l, i in zip(lines, order2):
         label, prob = l[3:].rsplit(" : ", 1)
         assert label == m.label(int(i)) and abs(float(prob) - rp2[0][i]) <= 0.011
+
+
+def test_cpp_accuracy_harness_matches_the_python_walk(pkg, binding, oracle, torch_gpu, tmp_path):
+    """examples/accuracy_main.cpp = the reference's tests/benchmark.cpp flow (class directories of *.JPEG files, ../classnames.json,
+    "file,class,prediction" lines, "Top-1 Accuracy: x%") on the drop-in header, classifying in batches through vit_predict_batch.  The
+    labels are arranged so that exactly the images whose oracle top-1 class we name as their directory count as correct."""
+    import json
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkgdir = os.path.join(root, "vit.cpp_amd")
+    exe = str(tmp_path / "accuracy")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(root, "examples", "accuracy_main.cpp"), "-I" + pkgdir, "-L" + pkgdir, "-lvitx", "-L/opt/rocm/lib",
+                        "-Wl,-rpath," + pkgdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    path = pkg.synth.cached_synthetic("vit_tiny_patch16_224", head_scale=4.0)
+    assets = os.path.join(root, "tests", "golden", "assets")
+    names = [f"class_{i:04d}" for i in range(1000)]
+    (tmp_path / "data" / "val").mkdir(parents=True)
+    json.dump(names, open(tmp_path / "data" / "classnames.json", "w"))
+    om = oracle.OracleModel(path)
+    files = ["tench.jpg", "magpie.jpeg", "apple.jpg", "polars.jpeg"]
+    files = [f for f in files if os.path.exists(os.path.join(assets, f))] or sorted(os.listdir(assets))[:4]
+    want_correct = 0
+    for k, a in enumerate(files):
+        u8 = binding.load_image(os.path.join(assets, a))
+        _, rp = om.forward(oracle.preprocess(u8, 224, "bicubic")[None], oracle.REF)
+        top = int(rp[0].argmax())
+        label = names[top] if k % 2 == 0 else names[(top + 1) % 1000]        # every second image is filed under a wrong class
+        want_correct += k % 2 == 0
+        (tmp_path / "data" / "val" / label).mkdir(exist_ok=True)
+        shutil.copy(os.path.join(assets, a), tmp_path / "data" / "val" / label / (os.path.splitext(a)[0] + ".JPEG"))
+    out = tmp_path / "pred.txt"
+    r = subprocess.run([exe, path, str(tmp_path / "data" / "val"), "0", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"Top-1 Accuracy: {100.0 * want_correct / len(files):g}%" in r.stdout, r.stdout
+    lines = open(out).read().split()
+    assert len(lines) == len(files) and all(len(l.split(",")) == 3 for l in lines)
+    assert sum(l.split(",")[1] == l.split(",")[2] for l in lines) == want_correct

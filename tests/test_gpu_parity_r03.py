@@ -94,10 +94,15 @@ def test_peaked_head_measured_deltas(pkg, binding, oracle, torch_gpu, head_scale
     model.close()
     d16, dbf, dbf_own = float(np.abs(out["f16"] - rp).max()), float(np.abs(out["bf16"] - rp).max()), float(np.abs(out["bf16"] - bp).max())
     _record(test="peaked_head", head_scale=head_scale, top1_prob=[round(float(x), 3) for x in rp.max(1)], oracle_summation_order_noise=noise,
-            f16_max_dprob_vs_ref=d16, bf16_max_dprob_vs_ref=dbf, bf16_max_dprob_vs_bf16_oracle=dbf_own)
-    assert (out["f16"].argmax(1) == rp.argmax(1)).all() and (out["bf16"].argmax(1) == rp.argmax(1)).all()
+            f16_max_dprob_vs_ref=d16, bf16_max_dprob_vs_ref=dbf, bf16_max_dprob_vs_bf16_oracle=dbf_own,
+            bf16_top1_agree=int((out["bf16"].argmax(1) == rp.argmax(1)).sum()), images=int(rp.shape[0]))
+    assert (out["f16"].argmax(1) == rp.argmax(1)).all()
     assert d16 <= max(3 * noise, 1e-3), (d16, noise)
     assert dbf <= 5e-2 and dbf_own <= 2.5e-2
+    # bf16 (8-bit significand) may swap two near-tied classes on a peaked head: where its top-1 differs, the reference's own margin between
+    # those two classes must be inside bf16's measured deviation
+    for b in np.nonzero(out["bf16"].argmax(1) != rp.argmax(1))[0]:
+        assert rp[b].max() - rp[b, out["bf16"][b].argmax()] <= 2 * dbf, (b, rp[b].max(), rp[b, out["bf16"][b].argmax()], dbf)
 
 
 def test_context_options_do_not_change_results(pkg, binding, torch_gpu):
@@ -213,3 +218,59 @@ def test_forward_ln_fusion_on_off_identical(pkg, binding, torch_gpu, name, n, dt
         ctx.close(); model.close()
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# One process, several GPUs (vitx_group_*): device-resident shards, persistent workers, top-k payload
+# ------------------------------------------------------------------------------------------------------------------
+def test_group_device_resident_shards_and_topk(pkg, binding, torch_gpu):
+    """vitx_group_forward_device on a one-GPU box (the RCCL path with one rank): the shard is already in HBM, the gathered result is read
+    from the device -- full probability rows, then the device-side top-5 pairs, which must equal vitx_topk of the same rows (descending,
+    ties by the lower class).  Repeated calls run on the SAME persistent worker set (no thread is created per call)."""
+    torch = torch_gpu
+    import ctypes
+    path = pkg.synth.cached_synthetic("vit_tiny_patch16_224", head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(7, 224, seed=77))
+    model = binding.Model(path)
+    ctx = binding.Context(model, device=0, max_batch=8, dtype=binding.F16)
+    want = ctx.forward(imgs); ctx.close()
+    grp = binding.Group(model, [0], 8, binding.F16)
+    d_imgs = torch.from_numpy(imgs).cuda()
+    for n in (7, 3, 7):
+        ptrs, n_max = grp.forward_device([d_imgs.data_ptr()], [n], topk=0)
+        assert n_max == n
+        got = np.empty((n, 1000), np.float32)
+        torch.cuda.synchronize()
+        assert ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptrs[0]), got.nbytes, 2) == 0
+        assert np.array_equal(got, want[:n])
+    ptrs, n_max = grp.forward_device([d_imgs.data_ptr()], [7], topk=5)
+    pairs = np.empty((7, 5, 2), np.float32)
+    assert ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(pairs.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptrs[0]), pairs.nbytes, 2) == 0
+    for b in range(7):
+        idx, val = binding.topk(want[b], 5)
+        assert list(pairs[b, :, 1].view(np.int32)) == idx
+        assert np.array_equal(pairs[b, :, 0], np.array(val, np.float32))
+    with pytest.raises(binding.VitxError):
+        grp.forward_device([d_imgs.data_ptr()], [9])              # 9 > 8 per device
+    with pytest.raises(binding.VitxError):
+        grp.forward_device([0], [3])                              # NULL pointer for a non-empty shard
+    with pytest.raises(ValueError):
+        grp.forward(imgs[:, :, :, 0])                             # wrong image shape (r02 advisor: unchecked buffer size)
+    grp.close(); model.close()
+
+
+def test_group_vitstr_output_size(pkg, binding, torch_gpu):
+    """r02 advisor (medium): for a ViTSTR file the group writes 25 x num_classes floats per image; the binding allocated num_classes."""
+    path = pkg.synth.cached_synthetic("vitstr_tiny_patch16_224", head_scale=4.0)
+    rng = np.random.default_rng(3)
+    imgs = rng.uniform(-1, 1, (5, 224, 224)).astype(np.float32)
+    model = binding.Model(path)
+    assert model.seq_len == 25
+    ctx = binding.Context(model, device=0, max_batch=8, dtype=binding.F16)
+    want = ctx.forward(imgs); ctx.close()
+    grp = binding.Group(model, [0], 8, binding.F16)
+    got = grp.forward(imgs)
+    assert got.shape == (5, 25, model.num_classes) and np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        grp.forward(np.zeros((2, 224, 224, 3), np.float32))       # a 3-channel batch for a one-channel model
+    grp.close(); model.close()

@@ -1,4 +1,5 @@
-"""Run a few ViT forwards (for rocprofv3): python tools/prof_forward.py [model] [batch] [steps] [dtype]"""
+"""Run a few ViT forwards (for rocprofv3): python tools/prof_forward.py [model] [batch] [steps] [dtype] [opt=val,...]
+(context options, e.g. streams=1 so that the sub-batches run back to back and kernel durations are exclusive)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +11,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dt = B.BF16 if (len(sys.argv) > 4 and sys.argv[4] == "bf16") else B.F16
 path = pkg.synth.cached_synthetic(name, head_scale=8.0)
 hp = pkg.synth.hparams_for(name)
-m = B.Model(path); ctx = B.Context(m, 0, batch, dt)
+opts = {k: int(v) for k, v in (o.split("=") for o in (sys.argv[5].split(",") if len(sys.argv) > 5 else []) if o)}
+m = B.Model(path); ctx = B.Context(m, 0, batch, dt, **opts)
 imgs = torch.randn((batch, hp.img_size, hp.img_size, 3), device="cuda")
 probs = torch.empty((batch, hp.num_classes), device="cuda")
 for _ in range(steps):

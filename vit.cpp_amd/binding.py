@@ -27,7 +27,7 @@ EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_uid", "vitx_model_hparams", "vitx_model_num_labels",
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_image_load", "vitx_image_decode", "vitx_image_free", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
-    "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
+    "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks",
     "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
@@ -95,6 +95,10 @@ def lib():
         L.vitx_group_free.argtypes = [vp]
         L.vitx_group_num_devices.argtypes = [vp]
         L.vitx_group_forward.argtypes = [vp, C.POINTER(C.c_float), ip, C.POINTER(C.c_float)]
+        L.vitx_group_out_floats.argtypes = [vp]
+        L.vitx_group_forward_device.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(ip), ip]
+        L.vitx_group_result.restype = C.c_void_p; L.vitx_group_result.argtypes = [vp, ip]
+        L.vitx_group_result_rows.argtypes = [vp]
         L.vitx_topk.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.vitx_profile_enable.argtypes = [vp, ip]
         L.vitx_profile_read.argtypes = [vp, C.POINTER(ProfEntry), ip, C.POINTER(ip)]
@@ -318,11 +322,24 @@ class Group:
         check(lib().vitx_group_create(model._h, devs, len(devices), max_batch_per_device, dtype, C.byref(self._h)), "vitx_group_create")
 
     def forward(self, imgs_hwc: np.ndarray) -> np.ndarray:
+        """Host images in, [n, C] probabilities out ([n, 25, C] for a ViTSTR file: vitx_group_out_floats floats per image)."""
         x = np.ascontiguousarray(imgs_hwc, np.float32); n = x.shape[0]
-        probs = np.empty((n, self.model.num_classes), np.float32)
+        _check_image_shape(self.model, x)
+        R = self.model.seq_len
+        probs = np.empty((n, self.model.num_classes) if R == 0 else (n, R, self.model.num_classes), np.float32)
+        assert probs[0].size == lib().vitx_group_out_floats(self._h)
         fp = C.POINTER(C.c_float)
         check(lib().vitx_group_forward(self._h, x.ctypes.data_as(fp), n, probs.ctypes.data_as(fp)), "vitx_group_forward")
         return probs
+
+    def forward_device(self, d_imgs: List[int], n_local: List[int], topk: int = 0) -> Tuple[List[int], int]:
+        """Device-resident shards (one device pointer and image count per device).  Returns (per-device pointers to the gathered result,
+        n_max): [n_devices][n_max][C] f32, or [n_devices][n_max][rows][topk] {f32, i32} pairs when topk > 0 (vitx_group_forward_device)."""
+        nd = lib().vitx_group_num_devices(self._h)
+        assert len(d_imgs) == nd and len(n_local) == nd
+        ptrs = (C.c_void_p * nd)(*[p or None for p in d_imgs]); cnt = (C.c_int * nd)(*n_local)
+        check(lib().vitx_group_forward_device(self._h, ptrs, cnt, topk), "vitx_group_forward_device")
+        return [lib().vitx_group_result(self._h, r) for r in range(nd)], lib().vitx_group_result_rows(self._h)
 
     def close(self):
         if getattr(self, "_h", None) and self._h:

@@ -566,6 +566,14 @@ static void split_batch(const vitx_ctx *c, int n, int ns, int *m) {
     const int n_cu = c->tune->n_cu;
     const int D = c->D;
     const bool ln = c->ln_fuse && c->slices[0].ln_sync;
+    if (ln) {
+        // LayerNorm-fusing residual GEMMs run rounds of (CUs / 8 / ntn) * ntn workgroups per XCD: the first sub-batch takes as many images as
+        // ONE such round holds (ViT-B on 256 CUs: 10 row blocks per XCD = 80 blocks = 103 images), the second the rest -- measured (r03a,
+        // interleaved, ms per 256-image forward): 72 | 103 | model's 110 | 128 images first = 9.95 | 9.90 | 10.09 | 10.21
+        const int ntn = D / 256, per_xcd = std::max(n_cu / 8, ntn) / ntn;
+        const int s1 = (int)((long)8 * per_xcd * 256 / c->N);
+        if (s1 >= n / 4 && s1 <= n / 2 && (long)s1 * c->N / 256 * ntn >= 128) { m[0] = s1; m[1] = n - s1; return; }
+    }
     auto layer = [&](int imgs) {
         const long rows = (long)imgs * c->N;
         const bool fl = ln && ((rows + 255) / 256) * (D / 256) >= 128;        // the fused kernel needs the wide path (is_wide, kernels.hip)

@@ -117,6 +117,9 @@ bool layernorm_supports(int D);
 // class softmax with the reference's fp16 (or bf16) exp rounding (vit.cpp:931)
 hipError_t launch_softmax(int dtype, const float *logits, float *probs, int rows, int cols, int ld, hipStream_t stream);
 hipError_t launch_preprocess(const void *u8, float *out, int n, int nx, int ny, int S, int bicubic, hipStream_t stream);
+// out[row][k] = {f32 probability, i32 class} of the k largest entries of probs[row][0..cols), descending, ties by the lower class index
+// (the sort of vit_predict, vit.cpp:1043-1057, on the device: the multi-GPU gather then moves 8 k bytes per row instead of 4 cols)
+hipError_t launch_topk(const float *probs, int rows, int cols, int k, void *out_pairs, hipStream_t stream);
 
 
 // internal: kernel families.  `prepare` = only set the dynamic-LDS attribute of the instantiation (device bring-up).

@@ -390,11 +390,18 @@ template <typename T, int NT>
 __global__ __launch_bounds__(256) void layernorm_fixup_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b, T *__restrict__ y,
                                                               int n_blocks, float eps, const unsigned *__restrict__ todo, unsigned epoch) {
     const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
-    for (int rb = 0; rb < n_blocks; ++rb) {
-        if (__builtin_nontemporal_load(todo + rb) != epoch) continue;
-        for (int r = wv; r < 256; r += nwv) {
-            const size_t row = (size_t)rb * 256 + r;
-            ln_row_tiled<T, NT>(x + row * (NT * 256), w, b, y + row * (NT * 256), eps, lane);
+    // 64 flags per pass, one per lane (r03a: a serial scan of the ~200 flags made this launch 16 us with nothing to do, 0.5 ms per forward)
+    for (int base = 0; base < n_blocks; base += 64) {
+        const int rb_l = base + lane;
+        const bool hit = rb_l < n_blocks && __builtin_nontemporal_load(todo + rb_l) == epoch;
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int rb = base + __builtin_ctzll(mask);
+            mask &= mask - 1;
+            for (int r = wv; r < 256; r += nwv) {
+                const size_t row = (size_t)rb * 256 + r;
+                ln_row_tiled<T, NT>(x + row * (NT * 256), w, b, y + row * (NT * 256), eps, lane);
+            }
         }
     }
 }
@@ -1074,14 +1081,14 @@ bool attention_single_pass_supports(int N) {
 bool attention_supports(int N, int D, int H) { return D == H * 64 && N > 0; }      // any token count
 // Kernel choice (measured, 128 x 12 heads bf16: 197 tokens 52 vs 55 us, 257 tokens 77 vs 92 us single-pass vs pipelined;
 // 64 x 16 heads x 577 tokens 282 vs 241 us -- profiles/r02_attention.txt):
-//   193..224 tokens with at least two items per CU: the persistent single-pass kernel; otherwise single-pass (all scores in registers)
-//   up to 288 tokens where instantiated, the pipelined two-pass kernel for everything else.
+//   193..224 tokens: the persistent single-pass kernel at EVERY batch size (its 16x16x32 products group the f32 sums differently from the
+//   32x32x16 kernels: one kernel per token count keeps an image's result independent of the batch it arrives in); otherwise single-pass
+//   (all scores in registers) up to 288 tokens where instantiated, the pipelined two-pass kernel for everything else.
 // t.attn_kernel (vitx_op_attention_ex, tests): ATTN_SINGLE / ATTN_FLOW / ATTN_PERSIST force one family.
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
-    // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax); needs
-    // enough items to keep every workgroup busy for a few rounds, otherwise the one-item-per-workgroup kernel starts faster
-    if ((t.attn_kernel == ATTN_PERSIST || (t.attn_kernel == ATTN_AUTO && (long)n_img * H >= 2L * t.n_cu)) && attention_persist_supports(n_img, N, D))
+    // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax)
+    if ((t.attn_kernel == ATTN_PERSIST || t.attn_kernel == ATTN_AUTO) && attention_persist_supports(n_img, N, D))
         return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.n_cu, stream) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.n_cu, stream);
     if (t.attn_kernel == ATTN_PERSIST) return hipErrorInvalidValue;
     const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_kernel == ATTN_SINGLE);
@@ -1172,6 +1179,37 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float *__restrict__ 
 hipError_t launch_softmax(int dtype, const float *logits, float *probs, int rows, int cols, int ld, hipStream_t stream) {
     if (dtype == DT_F16) hipLaunchKernelGGL(softmax_kernel<_Float16>, dim3(rows), dim3(256), 0, stream, logits, probs, cols, ld);
     else hipLaunchKernelGGL(softmax_kernel<__bf16>, dim3(rows), dim3(256), 0, stream, logits, probs, cols, ld);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top-k of every probability row (vit_predict's sort, vit.cpp:1043-1057): one wave per row, k selection passes; pass i takes the
+// largest entry that comes after pass i - 1's in the order (probability descending, class index ascending) -- no scratch, no ties lost.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ probs, int rows, int cols, int k, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *p = probs + (size_t)row * cols;
+    float pv = INFINITY; int pi = -1;
+    for (int it = 0; it < k; ++it) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = lane; i < cols; i += 64) {
+            const float v = p[i];
+            const bool after = v < pv || (v == pv && i > pi);            // not yet taken
+            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { out[((size_t)row * k + it) * 2] = bv; ((int *)out)[((size_t)row * k + it) * 2 + 1] = bi; }
+        pv = bv; pi = bi;
+    }
+}
+hipError_t launch_topk(const float *probs, int rows, int cols, int k, void *out_pairs, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0 || k <= 0 || k > cols) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, probs, rows, cols, k, (float *)out_pairs);
     return hipGetLastError();
 }
 
