@@ -186,10 +186,10 @@ def test_gemm_ln_fallback_path_gives_the_same_bits(binding, torch_gpu, test_mode
 
 
 @pytest.mark.parametrize("dtype_name", ["f16", "bf16"])
-@pytest.mark.parametrize("name,n", [("vit_base_patch16_224", 256), ("vit_base_patch16_224", 97), ("vit_large_patch16_384", 24)])
+@pytest.mark.parametrize("name,n", [("vit_base_patch16_224", 256), ("vit_base_patch16_224", 97), ("vit_large_patch16_384", 70)])
 def test_forward_ln_fusion_on_off_identical(pkg, binding, torch_gpu, name, n, dtype_name):
     """Whole forwards with the LayerNorms fused into proj / fc2 (default) and as their own launches (no_ln_fusion): identical logits, with
-    ragged last row blocks (97 x 197 and 24 x 577 rows are not multiples of 256: the fused GEMMs store the padded rows as well), two
+    ragged last row blocks (97 x 197 and 35 x 577 rows are not multiples of 256: the fused GEMMs store the padded rows as well), two
     sub-batch streams with two fused GEMMs in flight at once (256 images), both operand types; repeated forwards on one context stay
     identical, and the number of tiles that took the fix-up path is reported (it is 0 unless the two streams' GEMMs blocked each other)."""
     torch = torch_gpu
@@ -274,3 +274,28 @@ def test_group_vitstr_output_size(pkg, binding, torch_gpu):
     with pytest.raises(ValueError):
         grp.forward(np.zeros((2, 224, 224, 3), np.float32))       # a 3-channel batch for a one-channel model
     grp.close(); model.close()
+
+
+@pytest.mark.parametrize("ln_test", [1, 3])
+@pytest.mark.parametrize("name,n", [("vit_base_patch16_224", 256), ("vit_large_patch16_384", 70)])
+def test_forward_ln_fallback_fixed_by_the_consumer_gemm(pkg, binding, torch_gpu, name, n, ln_test):
+    """Whole forwards in which every fifth tile of every LayerNorm-fusing GEMM falls back (vitx_ctx_options::ln_test; 3 = with real 50 us
+    time-outs of its peers): the row blocks left behind are recomputed from X in the PROLOGUE of the GEMM that consumes them (qkv after
+    fc2, fc1 after proj: GemmArgs::fix) -- no launch in between -- and the logits equal the un-fused forward bit for bit."""
+    torch = torch_gpu
+    path = pkg.synth.cached_synthetic(name, head_scale=8.0)
+    hp = pkg.synth.hparams_for(name)
+    g = torch.Generator(device="cuda").manual_seed(7 + n)
+    imgs = torch.randn((n, hp.img_size, hp.img_size, 3), device="cuda", generator=g)
+    outs = {}
+    for key, opts in (("plain", {"no_ln_fusion": 1}), ("forced", {"ln_test": ln_test})):
+        model = binding.Model(path)
+        ctx = binding.Context(model, device=0, max_batch=n, dtype=binding.BF16, **opts)
+        probs = torch.empty((n, hp.num_classes), device="cuda"); logits = torch.empty_like(probs)
+        for rep in range(2):
+            ctx.forward_device(imgs.data_ptr(), n, probs.data_ptr(), logits.data_ptr(), 0); ctx.synchronize()
+        outs[key] = logits.clone()
+        fb = ctx.ln_fallbacks()
+        assert (fb > 0) == (key == "forced"), (key, fb)
+        ctx.close(); model.close()
+    assert torch.isfinite(outs["forced"]).all() and torch.equal(outs["plain"], outs["forced"])

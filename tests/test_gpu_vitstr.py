@@ -29,8 +29,14 @@ def test_forward_matches_oracle_f16(pkg, binding, oracle, torch_gpu, n):
     rl, rp = oracle.OracleModel(path).forward(imgs, oracle.REF)
     assert np.abs(probs - rp).max() <= 1e-3                      # north_star tolerance, every one of the 25 positions
     assert np.abs(logits - rl).max() <= 2.5e-2
+    # the decoded characters agree wherever the reference separates its two best classes by more than the tolerance (a random-init
+    # model has near-ties; a different f32 summation order -- e.g. the patch kernel's k order since r03 -- may flip those)
+    srt = np.sort(rp, -1)
+    decided = (srt[..., -1] - srt[..., -2]) > 2e-3
+    assert decided.mean() > 0.9 and ((probs.argmax(-1) == rp.argmax(-1)) | ~decided).all()
     for b in range(n):
-        assert _text(pkg, binding, probs[b])[0] == _text(pkg, binding, rp[b])[0]
+        if decided[b].all():
+            assert _text(pkg, binding, probs[b])[0] == _text(pkg, binding, rp[b])[0]
     # bf16 engine: same bound as the classifier's bf16 mode (test_gpu_e2e.test_forward_bf16_mode_tracks_its_own_oracle)
     ctxb = binding.Context(model, device=0, max_batch=n, dtype=binding.BF16)
     pb = ctxb.forward(imgs)

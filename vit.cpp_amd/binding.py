@@ -28,7 +28,7 @@ EXPORTS = [
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_image_load", "vitx_image_decode", "vitx_image_free", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
-    "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks",
+    "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
     "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
 
@@ -40,7 +40,7 @@ class HParams(C.Structure):
 
 class CtxOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("streams", C.c_int32), ("graph", C.c_int32), ("quant_on_host", C.c_int32), ("q4_fused_rows", C.c_int32),
-                ("split_first", C.c_int32), ("no_ln_fusion", C.c_int32)]
+                ("split_first", C.c_int32), ("no_ln_fusion", C.c_int32), ("ln_test", C.c_int32)]
 
 
 class ProfEntry(C.Structure):
@@ -115,6 +115,7 @@ def lib():
         L.vitx_op_gemm_q4.argtypes = [ip, ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, vp]
         L.vitx_ctx_weight_bytes.restype = C.c_size_t; L.vitx_ctx_weight_bytes.argtypes = [vp]
         L.vitx_ctx_ln_fallbacks.restype = C.c_longlong; L.vitx_ctx_ln_fallbacks.argtypes = [vp]
+        L.vitx_ctx_stream_retries.argtypes = [vp]
         L.vitx_op_gemm_ln.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, C.c_float, ip, ip, C.POINTER(ip), vp]
         L.vitx_probe_mfma.argtypes = [ip, ip, ip, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.vitx_model_in_channels.argtypes = [vp]; L.vitx_model_seq_len.argtypes = [vp]; L.vitx_ctx_out_rows.argtypes = [vp]
@@ -302,6 +303,10 @@ class Context:
     def ln_fallbacks(self) -> int:
         """GEMM tiles whose fused LayerNorm was left to the fix-up launch since the context was created (vitx_ctx_ln_fallbacks)."""
         return int(lib().vitx_ctx_ln_fallbacks(self._h))
+
+    def stream_retries(self) -> int:
+        """Internal sub-batch streams re-created because they did not run beside the caller's stream (vitx_ctx_stream_retries)."""
+        return int(lib().vitx_ctx_stream_retries(self._h))
 
     def profile_enable(self, on: bool = True) -> None:
         check(lib().vitx_profile_enable(self._h, int(on)))

@@ -137,6 +137,40 @@ __device__ __forceinline__ void ln_combine(const float (&mc)[LN_MAX_TILES], cons
     rstd = 1.0f / sqrtf((q + 256.0f * w) / (float)D + eps);
 }
 
+// One row of NT * 256 values by one wave, the tiled definition above: lane l holds piece l of each tile (w = l >> 4, j = (l >> 3) & 1,
+// k = l & 7): one fully coalesced 1 KiB load per tile.  Used by layernorm_kernel, layernorm_fixup_kernel (kernels.hip) and by the
+// prologue of a GEMM that consumes rows a LayerNorm-fusing GEMM left to the fix-up (gemm_pp.hip).
+template <typename T, int NT>
+__device__ __forceinline__ void ln_row_tiled(const float *__restrict__ xr, const float *__restrict__ w, const float *__restrict__ b, T *__restrict__ yr, float eps, int lane) {
+    f32x4 v[NT];
+    float mc[LN_MAX_TILES] = {0.0f, 0.0f, 0.0f, 0.0f}, m2[LN_MAX_TILES] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NT; ++c) v[c] = *(const f32x4 *)(xr + c * 256 + lane * 4);
+    auto tile_total = [&](float a) {       // a = this lane's piece value -> S_c (uniform)
+        const float s = a + __shfl_xor(a, 8);                      // s(w, k) = a(w, 0, k) + a(w, 1, k)
+        const float p = ln_sum8(s);                                // P(w), the same bits in the 16 lanes of wave column w
+        const float p0 = __shfl(p, 0), p1 = __shfl(p, 16), p2 = __shfl(p, 32), p3 = __shfl(p, 48);
+        return ((p0 + p1) + p2) + p3;
+    };
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        mc[c] = tile_total(ln_piece_sum(v[c])) * (1.0f / 256.0f);
+        m2[c] = tile_total(ln_piece_sq(v[c], mc[c]));
+    }
+    float mean, rstd;
+    ln_combine(mc, m2, NT, NT * 256, eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int idx = c * 256 + lane * 4;
+        const f32x4 ww = *(const f32x4 *)(w + idx), bb = *(const f32x4 *)(b + idx);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float t = (v[c][e] - mean) * rstd; t = t * ww[e]; o[e] = t + bb[e]; }
+        const typename Pair<T>::v2 lo = round_pair<T>(o[0], o[1]), hi = round_pair<T>(o[2], o[3]);
+        *(typename Elem<T>::v4 *)(yr + idx) = typename Elem<T>::v4{lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS tile image shared by the GEMM and attention kernels: rows of 64 elements (128 B = 8 slots of
 // 16 B).  Two rows form one 256-B bank line; the 16 slots of a line are XOR-ed with (line & 15) so a

@@ -31,10 +31,10 @@ using namespace vitx;
 namespace {
 
 enum ProfClass {
-    PC_PATCHIFY = 0, PC_GEMM_PATCH, PC_CLS, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_GEMM_PROJ, PC_GEMM_FC1, PC_GEMM_FC2,
+    PC_GEMM_PATCH = 0, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_GEMM_PROJ, PC_GEMM_FC1, PC_GEMM_FC2,
     PC_GEMM_HEAD, PC_SOFTMAX, PC_DEQUANT, PC_COUNT
 };
-const char *kProfNames[PC_COUNT] = {"patchify", "gemm_patch_embed", "cls_rows", "layernorm", "gemm_qkv_bias", "attention", "gemm_proj_resid",
+const char *kProfNames[PC_COUNT] = {"patch_embed", "layernorm", "gemm_qkv_bias", "attention", "gemm_proj_resid",
                                     "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_head", "softmax", "dequant_weights"};
 
 // A weight matrix kept in the file's block form on the device (quant.hip): `blocks` = N rows of K/32 blocks in the file's byte
@@ -86,7 +86,8 @@ struct vitx_ctx {
     // run on the wide persistent kernel.  vitx_ctx_options::no_ln_fusion turns it off (every LayerNorm its own launch; same bits).
     bool ln_fuse = true;
     unsigned ln_epoch = 0;               // tag of the next fused launch (unique per launch; 0 is never used)
-    unsigned ln_timeout = 20000;         // 200 us of the 100 MHz wall clock before a workgroup leaves its tile to the fix-up launch
+    unsigned ln_timeout = 20000;         // 200 us of the 100 MHz wall clock before a workgroup leaves its tile to the fix-up
+    int ln_test = 0;                     // vitx_ctx_options::ln_test (parity tests: forced time-outs, GemmLn::test)
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
     // (measured +10 % images/s at batch 256, tools/two_stream_probe.py).  Sub-batches are independent images.
@@ -111,6 +112,10 @@ struct vitx_ctx {
     int nslices = 1;
     std::vector<Slice> slices;
     hipEvent_t fork = nullptr;
+    hipStream_t probed_stream = nullptr;  // caller stream the internal streams were last checked against (ensure_concurrent)
+    bool probed = false;
+    int stream_retries = 0;               // internal streams re-created because they did not run beside the caller's stream
+    hipEvent_t probe_a = nullptr, probe_b = nullptr;
     float *img = nullptr;        // [max_batch][S][S][3] staging for the host entry point
     float *probs = nullptr;      // [max_batch][C]
     float *logits_all = nullptr; // [max_batch][C] staging for the host entry point
@@ -140,6 +145,8 @@ struct vitx_ctx {
         for (auto &ge : graphs) (void)hipGraphExecDestroy(ge.exec);
         for (auto &sl : slices) { if (sl.stream) (void)hipStreamDestroy(sl.stream); if (sl.done) (void)hipEventDestroy(sl.done); }
         if (fork) (void)hipEventDestroy(fork);
+        if (probe_a) (void)hipEventDestroy(probe_a);
+        if (probe_b) (void)hipEventDestroy(probe_b);
         if (prof_base) (void)hipEventDestroy(prof_base);
         if (trace_buf) (void)hipFree(trace_buf);
         for (void *p : allocs) (void)hipFree(p);
@@ -172,7 +179,8 @@ int upload_f32(vitx_ctx *c, const HostTensor *t, float **out, size_t n_pad = 0) 
 
 // [N][K] matrix -> operand type, rows padded to n_pad, cols to k_pad (zeros).  f16 file data is
 // forwarded bit-exact in F16 mode; everything else is decoded to f32 and rounded once (RNE).
-int upload_matrix(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad, int k_pad, void **out) {
+// patch_P > 0: the patch-embedding kernel [D][Cin * P * P]: its K axis is permuted to the image's memory order (patch_embed.hip)
+int upload_matrix(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad, int k_pad, void **out, int patch_P = 0, int patch_Cin = 0) {
     std::vector<uint16_t> h((size_t)n_pad * k_pad, 0);
     if (t->type == T_F16 && c->dtype == VITX_F16) {
         const uint16_t *src = (const uint16_t *)t->raw.data();
@@ -184,6 +192,7 @@ int upload_matrix(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad,
             for (int k = 0; k < K; ++k)
                 h[(size_t)n * k_pad + k] = c->dtype == VITX_F16 ? f32_to_f16_bits(f[(size_t)n * K + k]) : f32_to_bf16_bits(f[(size_t)n * K + k]);
     }
+    if (patch_P > 0) { std::vector<uint16_t> hp(h.size(), 0); patch_embed_permute_k(h.data(), hp.data(), Nrows, patch_Cin, patch_P, k_pad); h.swap(hp); }
     int rc = c->dmalloc(out, h.size() * 2, false);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(*out, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -238,12 +247,22 @@ struct ProfScope {
 };
 
 // `fused` != nullptr: W is that q4_0 matrix and the GEMM expands the blocks in its own LDS-fill path (small batches).
+// `fix`: the GemmLn of the LayerNorm-fusing GEMM that produced A (GemmArgs::fix); when the kernel this shape selects cannot recompute the
+// row blocks that GEMM left behind, they are fixed by a launch of their own first.
 int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
-         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr, const GemmLn *ln = nullptr) {
+         int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr, const GemmLn *ln = nullptr,
+         const GemmLn *fix = nullptr) {
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
     a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
     a.ln = ln;
+    if (fix) {
+        if (!fused && gemm_fix_capable(tune, a)) a.fix = fix;
+        else {
+            ProfScope ps(c, st, PC_LAYERNORM, 0, 0);
+            HIP_TRY(launch_layernorm_fixup(c->dtype, fix->x, fix->w, fix->b, fix->out, M, K, fix->eps, fix->todo, fix->epoch, st));
+        }
+    }
     double bytes = (double)M_real * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
     if (ln) bytes += (double)M_real * N * 2;
@@ -300,6 +319,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->quant_on_device = !opt.quant_on_host;
     c->q4_fused_rows = opt.q4_fused_rows;
     c->graphs_on = opt.graph != 0;
+    c->ln_test = opt.ln_test; if (opt.ln_test == 3) c->ln_timeout = 5000;      // real time-outs in the test: 50 us
     c->ln_fuse = !opt.no_ln_fusion && !opt.graph;        // a captured launch would replay its epoch tag: no fusion under the graph cache
 #ifdef VITX_LAB
     if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);
@@ -313,7 +333,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     if ((rc = upload_f32(c.get(), T("cls_token"), &c->cls))) return rc;
     if ((rc = upload_f32(c.get(), T("pos_embed"), &c->pos))) return rc;
     if ((rc = upload_f32(c.get(), T("patch_embed.proj.bias"), &c->pe_b, round_up(D, tn)))) return rc;
-    if ((rc = upload_matrix(c.get(), T("patch_embed.proj.weight"), D, c->Kpe, round_up(D, tn), c->Kpe_pad, &c->pe_w))) return rc;
+    if ((rc = upload_matrix(c.get(), T("patch_embed.proj.weight"), D, c->Kpe, round_up(D, tn), c->Kpe_pad, &c->pe_w, c->P, c->Cin))) return rc;
     c->layers.resize(c->L);
     for (int i = 0; i < c->L; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
@@ -368,15 +388,17 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
         }
         if (c->head_q.blocks && (rc = c->dmalloc(&sl.Wq_head, (size_t)c->head_q.n_pad * c->head_q.K * 2, false))) return rc;
         sl.tune = *c->tune;
-        if (ns > 1) {
-            // The runtime multiplexes all streams of one priority onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by
-            // default): in a process with many streams (torch's pool of 32) two slice streams can land on ONE queue and the
-            // sub-batches then run back to back (measured: 12.0 instead of 10.6 ms/step for ViT-B bs256).  Pools are per priority,
-            // so odd slices take the high-priority pool and even slices the normal one: never the same queue.
+        if (ns > 1 && i > 0) {
+            // Slice 0 runs on the CALLER's stream, slices 1.. on internal HIGH-priority streams.  The runtime multiplexes all streams of one
+            // priority onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), round-robin in creation order; a hardware queue
+            // executes its packets in order.  r02 gave slice 0 its own normal-priority stream: whenever that stream shared a hardware queue
+            // with the caller's (torch's pool of streams, a second context in the process ...), step k + 1's slice-0 kernels queued up behind
+            // the caller stream's wait for step k's slice 1, and the two sub-batches ran back to back -- measured r03: the 2nd and the 6th
+            // context created in one process ran 11.8 instead of 9.9 ms per forward.  Pools are per priority: the caller's stream (normal,
+            // unless the caller chose otherwise) and the internal ones (high, created back to back) can never share a queue.
             int least = 0, greatest = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            const int prio = (i & 1) ? greatest : 0;
-            HIP_TRY(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio));
+            HIP_TRY(hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, greatest));
             HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
     }
@@ -406,22 +428,16 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     };
     const int D = c->D, N = c->N, tm = c->tm, tn = c->tn, dt = c->dtype;
     const int tpi = c->g * c->g;
-    const Tuning &tn_ = (st == sl.stream && sl.stream) ? sl.tune : *c->tune;      // serialised / single-slice runs use the whole chip
-    const int Mp_real = n * tpi, Mp = round_up(Mp_real, tm);       // patch rows
+    const Tuning &tn_ = sl.tune;
+    const int Mp_real = n * tpi;                                   // patch rows
     const int M_real = n * N, M = round_up(M_real, tm);            // token rows
     const double eb = 2.0;                                          // operand bytes
 
-    // patch embedding: im2col -> GEMM(+bias, +pos, token scatter) ; cls rows      (vit.cpp:747-797)
-    {
-        ProfScope ps(c, st, PC_PATCHIFY, 0, (double)n * c->S * c->S * c->Cin * 4 + (double)Mp_real * c->Kpe_pad * eb);
-        HIP_TRY(launch_patchify(dt, (const float *)d_imgs, sl.Hbuf, n, c->S, c->P, c->Kpe_pad, Mp, st, c->Cin));
-    }
+    // patch embedding (vit.cpp:747-797) in one launch: im2col gather, GEMM, + bias + pos, token scatter, class rows (patch_embed.hip)
     int rc;
-    if ((rc = gemm(c, tn_, st, PC_GEMM_PATCH, EPI_PATCH, sl.Hbuf, c->pe_w, c->pe_b, sl.X, c->pos, Mp, Mp_real, D, round_up(D, tn), c->Kpe_pad,
-                   c->Kpe_pad, c->Kpe_pad, D, tpi, 4))) return rc;
     {
-        ProfScope ps(c, st, PC_CLS, 0, (double)n * D * 4);
-        HIP_TRY(launch_cls_rows(c->cls, c->pos, sl.X, n, N, D, st));
+        ProfScope ps(c, st, PC_GEMM_PATCH, 2.0 * Mp_real * (double)D * c->Kpe, (double)n * c->S * c->S * c->Cin * 4 + (double)M_real * D * 4);
+        HIP_TRY(launch_patch_embed(dt, (const float *)d_imgs, c->pe_w, c->pe_b, c->pos, c->cls, sl.X, n, c->S, c->P, c->Cin, D, round_up(D, tn), c->Kpe_pad, st));
     }
     if (!c->trace_ids.empty() && (rc = trace(0))) return rc;
     // Quantised matrices (block form in HBM): a q4_0 GEMM with few rows expands the blocks in its own LDS-fill path; everything else
@@ -460,16 +476,17 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         fuse = cs == hipStreamCaptureStatusNone && gemm_ln_fusable(tn_, probe) && gemm_ln_fusable(tn_, probe2);
     }
     // residual GEMM (+ the LayerNorm that follows it, fused when `fuse`; otherwise its own launch) -- proj + norm2, fc2 + the next norm1
-    auto resid_gemm_ln = [&](int pc, const void *A, const void *W, const float *bias, int K, const QuantW *fq, const float *lw, const float *lb, void *ln_out) -> int {
+    // `pend` receives the launch's GemmLn when the LayerNorm was fused: the GEMM that consumes ln_out next gets it as its `fix` argument
+    auto resid_gemm_ln = [&](int pc, const void *A, const void *W, const float *bias, int K, const QuantW *fq, const float *lw, const float *lb, void *ln_out, GemmLn *pend) -> int {
         int rc2;
+        pend->todo = nullptr;
         if (fuse && lw && !fq) {
             GemmLn ln{};
-            ln.w = lw; ln.b = lb; ln.out = ln_out; ln.eps = c->hp.eps; ln.sync = sl.ln_sync; ln.todo = sl.ln_todo; ln.fallbacks = sl.ln_todo + sl.ln_blocks;
+            ln.w = lw; ln.b = lb; ln.x = sl.X; ln.out = ln_out; ln.eps = c->hp.eps; ln.sync = sl.ln_sync; ln.todo = sl.ln_todo; ln.fallbacks = sl.ln_todo + sl.ln_blocks;
             if (++c->ln_epoch == 0) c->ln_epoch = 1;
-            ln.epoch = c->ln_epoch; ln.timeout = c->ln_timeout;
+            ln.epoch = c->ln_epoch; ln.timeout = c->ln_timeout; ln.test = c->ln_test;
             if ((rc2 = gemm(c, tn_, st, pc, EPI_BIAS_RESID, A, W, bias, sl.X, nullptr, M, M, D, round_up(D, tn), K, K, K, D, 0, 4, nullptr, &ln))) return rc2;
-            ProfScope ps(c, st, PC_LAYERNORM, 0, 0);
-            HIP_TRY(launch_layernorm_fixup(dt, sl.X, lw, lb, ln_out, M, D, c->hp.eps, sl.ln_todo, ln.epoch, st));
+            *pend = ln;
             return VITX_OK;
         }
         if ((rc2 = gemm(c, tn_, st, pc, EPI_BIAS_RESID, A, W, bias, sl.X, nullptr, M, M_real, D, round_up(D, tn), K, K, K, D, 0, 4, fq))) return rc2;
@@ -479,6 +496,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         }
         return VITX_OK;
     };
+    GemmLn fix_u{}, fix_u2{};          // fused LayerNorm launches whose output (U / U2) has not been consumed yet
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
         const void *Wl[W_PER_LAYER] = {w.qkv_w, w.proj_w, w.fc1_w, w.fc2_w};
@@ -497,18 +515,20 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
             if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
-        // qkv projection (vit.cpp:820-821)
-        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV]))) return rc;
+        // qkv projection (vit.cpp:820-821); `fix_u`: row blocks of U the previous layer's fc2 left to the fix-up are normalised in its prologue
+        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
+                       fix_u.todo ? &fix_u : nullptr))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
             if (!(skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873), then norm2 (vit.cpp:881-885) -> U2
-        if ((rc = resid_gemm_ln(PC_GEMM_PROJ, sl.U, Wl[W_PROJ], w.proj_b, D, Fl[W_PROJ], w.ln2_w, w.ln2_b, sl.U2))) return rc;
+        if ((rc = resid_gemm_ln(PC_GEMM_PROJ, sl.U, Wl[W_PROJ], w.proj_b, D, Fl[W_PROJ], w.ln2_w, w.ln2_b, sl.U2, &fix_u2))) return rc;
         // MLP (vit.cpp:889-900), then the NEXT layer's norm1 (vit.cpp:808-812) -> U; the last layer is followed by the cls-row norm instead
-        if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U2, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1]))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_FC1, EPI_BIAS_GELU, sl.U2, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, M, M_real, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1], nullptr,
+                       fix_u2.todo ? &fix_u2 : nullptr))) return rc;
         const LayerW *nx = il + 1 < c->L ? &c->layers[il + 1] : nullptr;
-        if ((rc = resid_gemm_ln(PC_GEMM_FC2, sl.Hbuf, Wl[W_FC2], w.fc2_b, 4 * D, Fl[W_FC2], nx ? nx->ln1_w : nullptr, nx ? nx->ln1_b : nullptr, sl.U))) return rc;
+        if ((rc = resid_gemm_ln(PC_GEMM_FC2, sl.Hbuf, Wl[W_FC2], w.fc2_b, 4 * D, Fl[W_FC2], nx ? nx->ln1_w : nullptr, nx ? nx->ln1_b : nullptr, sl.U, &fix_u))) return rc;
         if (!c->trace_ids.empty() && (rc = trace(il + 1))) return rc;
     }
     // cls pooling + final norm (vit.cpp:910-919): row b*N of X, i.e. row stride N*D.  ViTSTR (vitstr.cpp:864-895) keeps the first
@@ -620,6 +640,61 @@ static int forward_graph(vitx_ctx *c, hipStream_t st, const void *d_imgs, int n,
     return VITX_OK;
 }
 
+// Do the internal sub-batch streams really run BESIDE the caller's stream?  The HIP runtime maps streams onto a pool of hardware queues and
+// the queues onto the command processor's slots; which streams end up serialised depends on every other stream alive in the process
+// (measured r03, tools/ctx_order_probe.py: with earlier contexts still alive the 2nd and the 7th context of a process ran 11.6 instead of
+// 9.9 ms per forward -- with 8 hardware queues the 2nd, 4th and 6th, with 2 none; per-kernel times unchanged).  Nothing in the API tells,
+// so it is measured: a 40 us do-nothing kernel on each stream, forked and joined like a forward; ~40 us = concurrent, ~80 us = serialised.
+// For a serialised internal stream up to 8 candidate streams are created and kept alive TOGETHER (a stream created after another was
+// destroyed gets the same queue back), the first one that runs beside the caller's stream is adopted, the rest are destroyed.
+// Once per (context, caller stream), ~0.2 ms, synchronous; skipped while the caller captures a graph.
+static int probe_pair(vitx_ctx *c, hipStream_t st, hipStream_t s1, hipEvent_t done, float *best_ms) {
+    *best_ms = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {        // the first pass also wakes the queues up
+        HIP_TRY(hipEventRecord(c->probe_a, st));
+        HIP_TRY(hipStreamWaitEvent(s1, c->probe_a, 0));
+        HIP_TRY(launch_spin(40, s1));
+        HIP_TRY(hipEventRecord(done, s1));
+        HIP_TRY(launch_spin(40, st));
+        HIP_TRY(hipStreamWaitEvent(st, done, 0));
+        HIP_TRY(hipEventRecord(c->probe_b, st));
+        HIP_TRY(hipEventSynchronize(c->probe_b));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->probe_a, c->probe_b));
+        *best_ms = std::min(*best_ms, ms);
+    }
+    return VITX_OK;
+}
+static int ensure_concurrent(vitx_ctx *c, hipStream_t st, int ns) {
+    if (ns < 2 || (c->probed && c->probed_stream == st)) return VITX_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return VITX_OK; }
+    if (!c->probe_a) { HIP_TRY(hipEventCreate(&c->probe_a)); HIP_TRY(hipEventCreate(&c->probe_b)); }
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const float kSerialised = 0.064f;
+    for (int i = 1; i < ns; ++i) {
+        vitx_ctx::Slice &sl = c->slices[i];
+        float ms = 0.0f;
+        int rc = probe_pair(c, st, sl.stream, sl.done, &ms);
+        if (rc) return rc;
+        if (ms < kSerialised) continue;
+        hipStream_t cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        int pick = -1;
+        for (int k = 0; k < 8 && pick < 0; ++k) {
+            HIP_TRY(hipStreamCreateWithPriority(&cand[k], hipStreamNonBlocking, (k & 1) ? 0 : greatest));
+            ++c->stream_retries;
+            if ((rc = probe_pair(c, st, cand[k], sl.done, &ms))) break;
+            if (ms < kSerialised) pick = k;
+        }
+        for (int k = 0; k < 8; ++k) if (cand[k] && k != pick) (void)hipStreamDestroy(cand[k]);
+        if (rc) return rc;
+        if (pick >= 0) { (void)hipStreamDestroy(sl.stream); sl.stream = cand[pick]; }       // otherwise keep the original: nothing better exists
+    }
+    c->probed = true; c->probed_stream = st;
+    return VITX_OK;
+}
+
 int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, void *stream) {
     if (!c || !d_imgs || !d_probs) { set_error("vitx_forward_device: NULL argument"); return VITX_ERR_ARG; }
     if (n <= 0 || n > c->max_batch) { set_error("vitx_forward_device: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
@@ -639,22 +714,23 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     }
     int m[4];
     split_batch(c, n, ns, m);
-    // fork: every slice stream waits for the caller's stream, runs its contiguous sub-batch, and the caller's stream joins
+    if (!serial) { const int rc = ensure_concurrent(c, st, ns); if (rc) return rc; }
+    // fork: slices 1.. wait for the caller's stream and run their contiguous sub-batches on the internal streams, slice 0 runs on the caller's
+    // stream itself, which finally joins the others (slice 0 is enqueued LAST so that the host has already fed the other streams)
     if (!serial) HIP_TRY(hipEventRecord(c->fork, st));
-    int off = 0;
-    for (int i = 0; i < ns; ++i) {
+    int off[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < ns; ++i) off[i + 1] = off[i] + m[i];
+    for (int k = 0; k < ns; ++k) {
+        const int i = serial ? k : (k + 1) % ns;           // 1, 2, .., 0
         vitx_ctx::Slice &sl = c->slices[i];
-        hipStream_t ss = serial ? st : sl.stream;
-        if (!serial) HIP_TRY(hipStreamWaitEvent(sl.stream, c->fork, 0));
-        int rc = forward_slice(c, sl, ss, (const float *)d_imgs + (size_t)off * c->S * c->S * c->Cin, off, m[i], (float *)d_probs + (size_t)off * c->R * c->C,
-                               d_logits ? (float *)d_logits + (size_t)off * c->R * c->C : nullptr);
+        hipStream_t ss = (serial || i == 0) ? st : sl.stream;
+        if (!serial && i > 0) HIP_TRY(hipStreamWaitEvent(sl.stream, c->fork, 0));
+        int rc = forward_slice(c, sl, ss, (const float *)d_imgs + (size_t)off[i] * c->S * c->S * c->Cin, off[i], m[i], (float *)d_probs + (size_t)off[i] * c->R * c->C,
+                               d_logits ? (float *)d_logits + (size_t)off[i] * c->R * c->C : nullptr);
         if (rc) return rc;
-        if (!serial) {
-            HIP_TRY(hipEventRecord(sl.done, sl.stream));
-            HIP_TRY(hipStreamWaitEvent(st, sl.done, 0));
-        }
-        off += m[i];
+        if (!serial && i > 0) HIP_TRY(hipEventRecord(sl.done, sl.stream));
     }
+    if (!serial) for (int i = 1; i < ns; ++i) HIP_TRY(hipStreamWaitEvent(st, c->slices[i].done, 0));
     return VITX_OK;
 }
 
@@ -808,6 +884,7 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *a, const void *qs, const voi
     return VITX_OK;
 }
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c) { return c ? c->weight_bytes : 0; }
+int vitx_ctx_stream_retries(const vitx_ctx *c) { return c ? c->stream_retries : -1; }
 long long vitx_ctx_ln_fallbacks(vitx_ctx *c) {
     if (!c) return -1;
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;

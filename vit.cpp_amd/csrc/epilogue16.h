@@ -120,7 +120,7 @@ __device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro
 // ---- full-tile epilogue through a wave-private 4 KiB LDS patch: whole-row stores, an EXACT number of vector-memory instructions.
 //   * the accumulators hold one ROW per lane: a store straight from them touches 16 different 128-byte lines per instruction and
 //     the texture-address path serialises on lines (the ring kernels lost 20-27 % to it when they first moved to 16-wide tiles).
-//     So each 32-row block goes through the patch: written in the MFMA layout, read back with 8 lanes per 128-byte row, stored as
+//     So each 16-row block goes through the patch: written in the MFMA layout, read back with 8 lanes per 128-byte row, stored as
 //     whole lines (8 lines per instruction).  Patch rows are 128 B; 16-byte slots are XOR-ed with (row & 7): conflict-free reads,
 //     <= 2-way writes.
 //   * every store is one buffer_store_dwordx4 issued unconditionally (16 * NB / 4 for 16-bit outputs, 8 * NB for f32), so a
@@ -130,64 +130,70 @@ __device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro
 // soff8 = 8 rows, all in bytes of the output type; ro = buffer resource of the output matrix.
 template <typename T, int EPI, int NB, int AUX = 0>
 __device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const f32x4 (&bq)[4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane) {
+    // The 4 KiB patch is used as TWO halves of 16 rows x 128 B (r03): block b + 1 is converted and written into the other half between the
+    // issue of block b's read-back and its stores, so the LDS write -> read round trip and the stores' issue time hide under the next
+    // block's VALU work instead of serialising once per block.  (The LDS executes a wave's operations in issue order; the compiler-level
+    // fences keep the program order of accesses it cannot prove distinct.)
     const int l15 = lane & 15, g4 = lane >> 4;
     const int rd_off = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);         // row layout: row (lane>>3) + 8t, 16-byte piece lane&7
+    const int wr_row = l15 * 128, x16 = (l15 & 7) * 16;                                    // MFMA layout: this lane's row of a 16-row block
     pp_lds_fence();
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
         typedef typename Pair<T>::v2 v2;
+        auto convert_write = [&](int b) {            // 16-row block b = accumulator tile b of the wave
+            char *pb = patch + (b & 1) * 2048 + wr_row;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {                 // 32-row block i = tiles t = 2i, 2i + 1
-#pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f32x4 v = acc[2 * i + tp][u] + bq[u];
-                    v2 p0, p1;
-                    if constexpr (EPI == EPI_BIAS_GELU) { p0 = gelu_out_pair<T>(v[0], v[1]); p1 = gelu_out_pair<T>(v[2], v[3]); }
-                    else { p0 = round_pair<T>(v[0], v[1]); p1 = round_pair<T>(v[2], v[3]); }
-                    // columns u * 16 + 4 g4 .. + 3 -> bytes u * 32 + 8 g4 of the 128-byte patch row: 16-byte slot 2u + (g4 >> 1), half g4 & 1
-                    *(u32x2 *)(patch + prow * 128 + (((2 * u + (g4 >> 1)) * 16) ^ x16) + (g4 & 1) * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
-                }
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 v = acc[b][u] + bq[u];
+                v2 p0, p1;
+                if constexpr (EPI == EPI_BIAS_GELU) { p0 = gelu_out_pair<T>(v[0], v[1]); p1 = gelu_out_pair<T>(v[2], v[3]); }
+                else { p0 = round_pair<T>(v[0], v[1]); p1 = round_pair<T>(v[2], v[3]); }
+                // columns u * 16 + 4 g4 .. + 3 -> bytes u * 32 + 8 g4 of the 128-byte patch row: 16-byte slot 2u + (g4 >> 1), half g4 & 1
+                *(u32x2 *)(pb + (((2 * u + (g4 >> 1)) * 16) ^ x16) + (g4 & 1) * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
             }
             pp_lds_fence();
-            u32x4 d[4];
+        };
+        convert_write(0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) d[t] = *(const u32x4 *)(patch + t * 1024 + rd_off);
+        for (int b = 0; b < 2 * NB; ++b) {
+            u32x4 d[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) d[t] = *(const u32x4 *)(patch + (b & 1) * 2048 + t * 1024 + rd_off);
             pp_lds_fence();
+            if (b + 1 < 2 * NB) convert_write(b + 1);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) pp_store_b128<AUX>(d[t], ro, voff, soff + (i * 4 + t) * soff8);
+            for (int t = 0; t < 2; ++t) pp_store_b128<AUX>(d[t], ro, voff, soff + (b * 2 + t) * soff8);
         }
-    } else {       // f32 outputs: one 32 x 32 block (4 KiB) per pass
-        u32x4 res[2][4];                            // residual rows of the current and the next pass (loads run one pass ahead)
-        auto load_res = [&](int c, u32x4 (&dst)[4]) {
-            const int i = c >> 1, j = c & 1;
+    } else {       // f32 outputs: one 16 x 32 block (2 KiB) per pass, pass c = (16-row block c >> 1, 32-column half c & 1)
+        u32x4 res[2][2];                            // residual rows of the current and the next pass (loads run one pass ahead)
+        auto load_res = [&](int c, u32x4 (&dst)[2]) {
+            const int b = c >> 1, j = c & 1;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+            for (int t = 0; t < 2; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (b * 2 + t) * soff8, 0);
+        };
+        auto write_pass = [&](int c) {
+            const int b = c >> 1, j = c & 1;
+            char *pb = patch + (c & 1) * 2048 + wr_row;
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu)          // columns (2j + uu) * 16 + 4 g4 of the wave = (uu * 16 + 4 g4) of this 32-column half: slot 4 uu + g4
+                *(f32x4 *)(pb + (((4 * uu + g4) * 16) ^ x16)) = acc[b][2 * j + uu] + bq[2 * j + uu];
+            pp_lds_fence();
         };
         if constexpr (EPI == EPI_BIAS_RESID) load_res(0, res[0]);
+        write_pass(0);
 #pragma unroll
-        for (int c = 0; c < 2 * NB; ++c) {
-            const int i = c >> 1, j = c & 1;
-            if constexpr (EPI == EPI_BIAS_RESID) { if (c + 1 < 2 * NB) load_res(c + 1, res[(c + 1) & 1]); }
+        for (int c = 0; c < 4 * NB; ++c) {
+            const int b = c >> 1, j = c & 1;
+            if constexpr (EPI == EPI_BIAS_RESID) { if (c + 1 < 4 * NB) load_res(c + 1, res[(c + 1) & 1]); }
+            f32x4 d[2];
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
-#pragma unroll
-                for (int uu = 0; uu < 2; ++uu) {        // columns (2j + uu) * 16 + 4 g4 of the wave = (uu * 16 + 4 g4) of this 32-column block: slot 4 uu + g4
-                    const f32x4 v = acc[2 * i + tp][2 * j + uu] + bq[2 * j + uu];
-                    *(f32x4 *)(patch + prow * 128 + (((4 * uu + g4) * 16) ^ x16)) = v;
-                }
-            }
+            for (int t = 0; t < 2; ++t) d[t] = *(const f32x4 *)(patch + (c & 1) * 2048 + t * 1024 + rd_off);
             pp_lds_fence();
-            f32x4 d[4];
+            if (c + 1 < 4 * NB) write_pass(c + 1);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) d[t] = *(const f32x4 *)(patch + t * 1024 + rd_off);
-            pp_lds_fence();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < 2; ++t) {
                 if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
-                pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
+                pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (b * 2 + t) * soff8);
             }
         }
     }

@@ -66,7 +66,8 @@ template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (E
 // ---- EPI_BIAS_RESID + LayerNorm of the finished rows (GemmLn, kernels.h), for one full 256 x 256 tile of the persistent kernel.
 // Statistics follow device_common.h "LayerNorm statistics by 256-column tiles": this workgroup's tile is tile c = n0 / 256 of its rows;
 // wave column w = the 64-column chunk, accumulator half j and 16-byte piece k = lane & 7 of the staged row layout name the pieces.
-//   passes   the staged f32 epilogue (bias, + residual, whole-line X stores); the final values stay in the accumulator registers
+//   passes   the staged f32 epilogue (bias, + residual; 16 passes of 16 rows x 32 columns) into row layout; the final values stay in the
+//            accumulator registers and are stored as whole lines at the very end
 //   (1)      tile sums: in-lane over j, ln_sum8 over k, the four wave columns through LDS            -> mean_c   [2 barriers]
 //   (2)      centred sums of squares the same way                                                    -> M2_c     [1 barrier]
 //   (3)      one thread per row publishes {mean_c, M2_c} as two 8-byte granules {value, tag = epoch} (ONE sc1 store each: the data
@@ -99,43 +100,47 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
     int *fail = (int *)(sb + 15360);
     const int rd_off = lr * 128 + ((lk ^ (lr & 7)) * 16);     // row layout of the patch: row lr + 8 t, 16-byte piece lk
     const int mb = m0 / BM, ct = n0 / BN;
-    if (tid == 0) *fail = 0;
     // ---- passes (epilogue16_staged, f32 + residual), keeping the stored values: xv(c, t) = row (c >> 1) * 32 + lr + 8 t, columns (c & 1) * 32 + 4 lk ..
     // (register budget: the kernel sits at 256.  The bias is therefore added in ROW layout -- 2 x 4 values per lane instead of the 4 x 4 of
     // the accumulator layout, same (acc + bias) + x order -- and nothing but xv accumulates across the passes.)
-    // xv(c, t) ALIASES the accumulator registers pass c has just consumed: for hipcc the accumulators stay live into the next tile's K loop
-    // (they are re-zeroed under a run-time condition), so a second 128-register array could only be spilled
-#define xv(c, t) acc[2 * ((c) >> 1) + ((t) >> 1)][2 * ((c) & 1) + ((t) & 1)]
+    // xv(b, j, t) ALIASES the accumulator registers pass (b, j) has just consumed: for hipcc the accumulators stay live into the next tile's
+    // K loop (they are re-zeroed under a run-time condition), so a second 128-register array could only be spilled.
+    // xv(b, j, t) = row 16 b + lr + 8 t of the wave's 128, columns 32 j + 4 lk .. + 3 of its 64.
+#define xv(b, j, t) acc[b][2 * (j) + (t)]
     {
         f32x4 br[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) br[j] = *(const f32x4 *)(patch + j * 128 + lk * 16);       // bias of columns j * 32 + 4 lk .. of the wave's 64 (LDS-DMA'd during the K loop)
         pp_lds_fence();
-        u32x4 res[2][4];
-        auto load_res = [&](int c, u32x4 (&dst)[4]) {
-            const int i = c >> 1, j = c & 1;
+        const int wr_row = l15 * 128, x16 = (l15 & 7) * 16;
+        u32x4 res[2][2];
+        auto load_res = [&](int c, u32x4 (&dst)[2]) {
+            const int b = c >> 1, j = c & 1;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (i * 4 + t) * soff8, 0);
+            for (int t = 0; t < 2; ++t) dst[t] = __builtin_amdgcn_raw_buffer_load_b128(ro, voff + j * 128, soff + (b * 2 + t) * soff8, 0);
+        };
+        auto write_pass = [&](int c) {          // pass c = (16-row block c >> 1, 32-column half c & 1) into half c & 1 of the patch (epilogue16_staged)
+            const int b = c >> 1, j = c & 1;
+            char *pb = patch + (c & 1) * 2048 + wr_row;
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) *(f32x4 *)(pb + (((4 * uu + g4) * 16) ^ x16)) = acc[b][2 * j + uu];
+            pp_lds_fence();
         };
         load_res(0, res[0]);
+        write_pass(0);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int i = c >> 1, j = c & 1;
-            if (c + 1 < 8) load_res(c + 1, res[(c + 1) & 1]);
+        for (int c = 0; c < 16; ++c) {
+            const int b = c >> 1, j = c & 1;
+            if (c + 1 < 16) load_res(c + 1, res[(c + 1) & 1]);
+            f32x4 d[2];
 #pragma unroll
-            for (int tp = 0; tp < 2; ++tp) {
-                const int prow = tp * 16 + l15, x16 = (prow & 7) * 16;
-#pragma unroll
-                for (int uu = 0; uu < 2; ++uu) *(f32x4 *)(patch + prow * 128 + (((4 * uu + g4) * 16) ^ x16)) = acc[2 * i + tp][2 * j + uu];
-            }
+            for (int t = 0; t < 2; ++t) d[t] = *(const f32x4 *)(patch + (c & 1) * 2048 + t * 1024 + rd_off);
             pp_lds_fence();
+            if (c + 1 < 16) write_pass(c + 1);          // reads the accumulators of pass c + 1: other registers than xv(b, j, .) below
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xv(c, t) = *(const f32x4 *)(patch + t * 1024 + rd_off);
-            pp_lds_fence();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xv(c, t) = (xv(c, t) + br[j]) + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
-                pp_store_b128(__builtin_bit_cast(u32x4, xv(c, t)), ro, voff + j * 128, soff + (i * 4 + t) * soff8);
+            for (int t = 0; t < 2; ++t) {
+                xv(b, j, t) = (d[t] + br[j]) + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
+                asm volatile("" : "+v"(xv(b, j, t)));      // materialise NOW: with its first use far below, LLVM sinks the add and keeps (spills) all 32 residual loads
             }
         }
     }
@@ -143,14 +148,25 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
     f32x4 gw[2], gb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) { gw[j] = *(const f32x4 *)(ln.w + n0 + wc * 64 + j * 32 + lk * 4); gb[j] = *(const f32x4 *)(ln.b + n0 + wc * 64 + j * 32 + lk * 4); }
+    // The X tile is stored AFTER the statistics exchange (r03c): stores issued before it sat in front of the granule stores and of the
+    // polling loads in this CU's (in-order) vector-memory queue -- the hand-off then cost the drain of 256 KiB per workgroup on both sides.
+    auto store_x = [&]() {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int b = c >> 1, j = c & 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) pp_store_b128(__builtin_bit_cast(u32x4, xv(b, j, t)), ro, voff + j * 128, soff + (b * 2 + t) * soff8);
+        }
+    };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    if (tid == 0) *fail = 0;
     // ---- (1) tile sums -> mean_c
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float p = ln_sum8(ln_piece_sum(xv(2 * i, t)) + ln_piece_sum(xv(2 * i + 1, t)));
-            if (lk == 0) part[wc * 256 + wr * 128 + i * 32 + t * 8 + lr] = p;
+        for (int t = 0; t < 2; ++t) {
+            const float p = ln_sum8(ln_piece_sum(xv(b, 0, t)) + ln_piece_sum(xv(b, 1, t)));
+            if (lk == 0) part[wc * 256 + wr * 128 + b * 16 + t * 8 + lr] = p;
             __builtin_amdgcn_sched_barrier(0);      // one row at a time: hipcc otherwise interleaves all 16 and spills the tile it is reducing
         }
     lds_barrier();
@@ -158,12 +174,12 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
     lds_barrier();
     // ---- (2) centred sums of squares -> M2_c
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float mc = cmean[wr * 128 + i * 32 + t * 8 + lr];
-            const float q = ln_sum8(ln_piece_sq(xv(2 * i, t), mc) + ln_piece_sq(xv(2 * i + 1, t), mc));
-            if (lk == 0) part[wc * 256 + wr * 128 + i * 32 + t * 8 + lr] = q;        // every wave read cmean, not part, since the last barrier
+        for (int t = 0; t < 2; ++t) {
+            const float mc = cmean[wr * 128 + b * 16 + t * 8 + lr];
+            const float q = ln_sum8(ln_piece_sq(xv(b, 0, t), mc) + ln_piece_sq(xv(b, 1, t), mc));
+            if (lk == 0) part[wc * 256 + wr * 128 + b * 16 + t * 8 + lr] = q;        // every wave read cmean, not part, since the last barrier
             __builtin_amdgcn_sched_barrier(0);
         }
     lds_barrier();
@@ -206,6 +222,7 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
             __hip_atomic_fetch_add(ln.fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         lds_barrier();     // `fail` and the statistics are re-used by the next tile: nobody may still be reading them
+        store_x();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return false;
     }
@@ -224,23 +241,24 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
         // ln.out is [M][N] of T with the GEMM's row length: the X offsets halve (f32 -> 16 bit)
         const int uoff = voff >> 1, usoff = soff >> 1, usoff8 = soff8 >> 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int b = 0; b < 8; ++b)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f32x2 mr = *(const f32x2 *)(fin + (wr * 128 + i * 32 + t * 8 + lr) * 2);
+            for (int t = 0; t < 2; ++t) {
+                const f32x2 mr = *(const f32x2 *)(fin + (wr * 128 + b * 16 + t * 8 + lr) * 2);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float o[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { float v = (xv(2 * i + j, t)[e] - mr[0]) * mr[1]; v = v * gw[j][e]; o[e] = v + gb[j][e]; }
+                    for (int e = 0; e < 4; ++e) { float v = (xv(b, j, t)[e] - mr[0]) * mr[1]; v = v * gw[j][e]; o[e] = v + gb[j][e]; }
                     const typename Pair<T>::v2 lo = round_pair<T>(o[0], o[1]), hi = round_pair<T>(o[2], o[3]);
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, ru, uoff + j * 64, usoff + (i * 4 + t) * usoff8, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, ru, uoff + j * 64, usoff + (b * 2 + t) * usoff8, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
     }
+    store_x();
     lds_barrier();         // the statistics area (and `fail`) is re-used by the next tile, and the ring slot is re-staged soon after
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // at most the 32 U stores stay in flight (X stores of lanes that did not poll included)
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // the 32 normalised-row stores are older and have landed; at most the 32 X stores stay in flight
     return true;
 #undef xv
 }
@@ -294,6 +312,31 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         }
     };
     if (my_tiles <= 0) return;
+
+    // ---- consumer side of a LayerNorm-fusing GEMM (GemmArgs::fix): A = that GEMM's normalised rows.  Row blocks it left to the fix-up
+    // (a peer workgroup did not answer in time) are recomputed from X HERE, by every workgroup for the row blocks of ITS OWN tiles, before
+    // anything of A is loaded: no launch in between, no waiting on another workgroup (several redo a block: the same bits).
+    if constexpr (!LNF) {
+        if (ln.todo) {
+            bool any = false;
+            for (int r = 0; r < my_tiles; ++r) {
+                int m0, n0; tile_origin(r, m0, n0);
+                if (__builtin_nontemporal_load(ln.todo + m0 / BM) != ln.epoch) continue;        // workgroup-uniform
+                any = true;
+                const int D = g.K;
+                for (int row = m0 + wave; row < m0 + BM; row += 8) {
+                    const float *xr = ln.x + (size_t)row * D; T *yr = (T *)ln.out + (size_t)row * D;
+                    switch (D >> 8) {
+                    case 1: ln_row_tiled<T, 1>(xr, ln.w, ln.b, yr, ln.eps, lane); break;
+                    case 2: ln_row_tiled<T, 2>(xr, ln.w, ln.b, yr, ln.eps, lane); break;
+                    case 3: ln_row_tiled<T, 3>(xr, ln.w, ln.b, yr, ln.eps, lane); break;
+                    default: ln_row_tiled<T, 4>(xr, ln.w, ln.b, yr, ln.eps, lane); break;
+                    }
+                }
+            }
+            if (any) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        }
+    }
 
     // ---- LDS-DMA: physical 16-B piece p = i*512 + tid of a half-tile image <-> logical (image row, slot)
     int aoff[STAGE_OPS], woff[STAGE_OPS];
@@ -502,7 +545,7 @@ static hipError_t launch_pp_inst(const GemmArgs &a, int n_cu, hipStream_t stream
     int cap = n_cu & ~7;                             // the tile walk keeps a workgroup on one XCD: grid is a multiple of 8
     if (cap <= 0) cap = 256;
     const int grid = ntiles < cap ? ntiles : cap;
-    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI, FLAGS>), dim3(grid), dim3(512), pp::LDS_ALL, stream, a, GemmLn{});
+    hipLaunchKernelGGL((gemm_pp_kernel<T, EPI, FLAGS>), dim3(grid), dim3(512), pp::LDS_ALL, stream, a, a.fix ? *a.fix : GemmLn{});
     return hipGetLastError();
 }
 // Persistent grid of the LayerNorm-fusing GEMM: 8 XCDs x wgx workgroups, wgx a multiple of the ntn column tiles (so the tiles of a row

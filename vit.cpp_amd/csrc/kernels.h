@@ -33,6 +33,11 @@ struct GemmArgs {
     int group_m;  // ping-pong kernel: m-tiles per raster group (0 = the default, 8)
     // LayerNorm of the output rows fused into an EPI_BIAS_RESID GEMM on the ping-pong kernel (gemm_ln_fusable()): `ln` != nullptr.
     const struct GemmLn *ln;
+    // A GEMM whose A operand is the output of a LayerNorm-fusing GEMM: `fix` = that launch's GemmLn (+ x = its X).  Before it loads anything,
+    // every workgroup normalises the row blocks IT is going to read that were left behind (todo[rb] == epoch) -- no extra launch, no
+    // dependency between workgroups (several may redo the same block: identical bits).  gemm_fix_capable() says whether the kernel the
+    // shape selects does this; otherwise the caller launches launch_layernorm_fixup.
+    const struct GemmLn *fix;
 };
 
 // The LayerNorm that follows a residual GEMM (vit.cpp:881-885 after proj, :808-812 of the next layer after fc2), computed by the
@@ -45,6 +50,7 @@ struct GemmArgs {
 // normalises exactly those row blocks from X with the stand-alone arithmetic -- the same bits (device_common.h "LayerNorm statistics").
 struct GemmLn {
     const float *w, *b;           // [N]
+    const float *x;               // consumer-side fix only (GemmArgs::fix): the f32 rows [M][N] the statistics are recomputed from
     void *out;                    // [M][N] operand type
     float eps;
     unsigned long long *sync;     // [M / 256][N / 256][256][2] granules {value bits, tag = epoch}, zeroed once
@@ -94,6 +100,8 @@ hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, h
 // true when launch_gemm runs this EPI_BIAS_RESID GEMM on the ping-pong kernel in one launch with whole rows (N == N_pad == ldo,
 // N / 256 <= 4 column tiles), so that GemmArgs::ln may be set; the caller then launches launch_layernorm_fixup instead of launch_layernorm
 bool gemm_ln_fusable(const Tuning &t, const GemmArgs &a);
+// true when launch_gemm runs this GEMM on the ping-pong kernel, which honours GemmArgs::fix (K = the LayerNorm's row length, 256 .. 1024)
+bool gemm_fix_capable(const Tuning &t, const GemmArgs &a);
 // persistent grid of that GEMM (for the sub-batch cost model): workgroups per XCD are a multiple of the column tiles
 int gemm_ln_grid(int n_cu, int M, int N);
 // normalises the row blocks a fused GEMM left behind (todo[rb] == epoch) from x; a few microseconds when there are none
@@ -101,11 +109,12 @@ hipError_t launch_layernorm_fixup(int dtype, const float *x, const float *w, con
 int gemm_tile_m();   // M granularity the GEMM needs (buffer row padding)
 int gemm_tile_n();
 
-// im2col of the f32 HWC image into dtype rows [n_img*g*g][Kpad], k = c*P*P + ky*P + kx (vit.cpp:759-772)
-// (Cin = 3: RGB classifier input; 1: the grey ViTSTR input, extensions/vitstr.cpp/vitstr.cpp:713-731)
-hipError_t launch_patchify(int dtype, const float *img, void *out, int n_img, int S, int P, int Kpad, int rows_pad, hipStream_t stream, int Cin = 3);
-// X[b*N + 0][:] = cls + pos[0]  (vit.cpp:794-797)
-hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_img, int N, int D, hipStream_t stream);
+// Patch embedding in one launch (patch_embed.hip; vit.cpp:747-797): X[b * N + 1 + t][:] = W . patch(b, t) + bias + pos[1 + t], X[b * N][:] = cls + pos[0].
+// img: f32 HWC [n_img][S][S][Cin] (Cin = 3: RGB classifier input; 1: the grey ViTSTR input, extensions/vitstr.cpp/vitstr.cpp:713-731);
+// w_perm: the [n_pad][k_pad] operand-type kernel with its K axis permuted by patch_embed_permute_k (host side, at upload); pos [N][D], cls [D].
+hipError_t launch_patch_embed(int dtype, const float *img, const void *w_perm, const float *bias, const float *pos, const float *cls, float *X,
+                              int n_img, int S, int P, int Cin, int D, int n_pad, int k_pad, hipStream_t stream, bool prepare = false);
+void patch_embed_permute_k(const uint16_t *w, uint16_t *w_perm, int N, int Cin, int P, int k_pad);
 // y[r][:] (dtype) = LN(x[r*ldx ...]) * w + b   (vit.cpp:808-812)
 // group > 1: input row r = x + (r / group) * gstride + (r % group) * ldx (the first `group` tokens of every image: ViTSTR head)
 hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream, int group = 1, long gstride = 0);
@@ -120,6 +129,8 @@ hipError_t launch_preprocess(const void *u8, float *out, int n, int nx, int ny, 
 // out[row][k] = {f32 probability, i32 class} of the k largest entries of probs[row][0..cols), descending, ties by the lower class index
 // (the sort of vit_predict, vit.cpp:1043-1057, on the device: the multi-GPU gather then moves 8 k bytes per row instead of 4 cols)
 hipError_t launch_topk(const float *probs, int rows, int cols, int k, void *out_pairs, hipStream_t stream);
+// one workgroup that does nothing for `microseconds` of the 100 MHz wall clock (stream-concurrency probe of the execution context)
+hipError_t launch_spin(int microseconds, hipStream_t stream);
 
 
 // internal: kernel families.  `prepare` = only set the dynamic-LDS attribute of the instantiation (device bring-up).

@@ -200,6 +200,9 @@ bool gemm_ln_fusable(const Tuning &t, const GemmArgs &a) {
     return t.gemm_cfg < 0 && !t.gemm_split && !t.pp_flags && a.M > 0 && is_wide(a) && gemm_pp_supports(a) && a.N == a.ldo && a.N == a.N_pad && a.N % 256 == 0 &&
            a.N / 256 <= LN_MAX_TILES && (size_t)a.M * a.ldo * 4 < 0xf0000000u;
 }
+bool gemm_fix_capable(const Tuning &t, const GemmArgs &a) {
+    return t.gemm_cfg < 0 && !t.gemm_split && !t.pp_flags && a.M > 0 && is_wide(a) && gemm_pp_supports(a) && a.K == a.lda && a.K % 256 == 0 && a.K / 256 <= LN_MAX_TILES;
+}
 static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a0, hipStream_t stream) {
     GemmArgs a = a0; a.group_m = t.group_m;
     if (a.ln) return (epi == EPI_BIAS_RESID && gemm_ln_fusable(t, a)) ? launch_gemm_pp(dtype, epi, a, t.n_cu, stream, 0) : hipErrorInvalidValue;
@@ -210,6 +213,7 @@ static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArg
 hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, hipStream_t stream) {
     if (a.M <= 0) return hipErrorInvalidValue;
     if (a.ln && !gemm_ln_fusable(t, a)) return hipErrorInvalidValue;      // the caller asks gemm_ln_fusable first
+    if (a.fix && !gemm_fix_capable(t, a)) return hipErrorInvalidValue;     // ... and gemm_fix_capable
     int cfg = t.gemm_cfg;
     if (cfg == 1) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     if (cfg > 1) return gemm_ring_supports(a, cfg) ? launch_gemm_ring(t, dtype, epi, a, cfg, stream) : hipErrorInvalidValue;
@@ -251,52 +255,6 @@ hipError_t launch_gemm_q4(int dtype, int epi, const GemmArgs &a, hipStream_t str
 }
 
 // ------------------------------------------------------------------------------------------------
-// im2col (vit.cpp:759-772): out[b*g*g + t][k], k = c*P*P + ky*P + kx, token t = px + g*py, from the HWC
-// f32 image; rounded to the operand type exactly where ggml's im2col emits fp16.  8 elements (16 B)
-// per thread; columns k >= 3*P*P and rows >= n_img*g*g are zero padding.
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ img, T *__restrict__ out, int n_img, int S, int P, int Kpad, int rows_pad, int Cin) {
-    const int g = S / P, tpi = g * g, K = Cin * P * P, PP = P * P;
-    const int chunks_per_row = Kpad / 8;
-    const long total = (long)rows_pad * chunks_per_row;
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(id / chunks_per_row), kc = (int)(id % chunks_per_row);
-        typename Elem<T>::v8 v;
-        const int b = row / tpi, t = row - b * tpi, py = t / g, px = t - py * g;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = kc * 8 + j;
-            float x = 0.0f;
-            if (row < n_img * tpi && k < K) {
-                const int c = k / PP, rem = k - c * PP, ky = rem / P, kx = rem - ky * P;
-                x = img[(((size_t)b * S + (py * P + ky)) * S + (px * P + kx)) * Cin + c];
-            }
-            v[j] = (T)x;
-        }
-        *(typename Elem<T>::v8 *)(out + (size_t)row * Kpad + kc * 8) = v;
-    }
-}
-
-hipError_t launch_patchify(int dtype, const float *img, void *out, int n_img, int S, int P, int Kpad, int rows_pad, hipStream_t stream, int Cin) {
-    const long total = (long)rows_pad * (Kpad / 8);
-    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    if (dtype == DT_F16) hipLaunchKernelGGL(patchify_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, img, (_Float16 *)out, n_img, S, P, Kpad, rows_pad, Cin);
-    else hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, img, (__bf16 *)out, n_img, S, P, Kpad, rows_pad, Cin);
-    return hipGetLastError();
-}
-
-// X[b*N][:] = cls_token + pos_embed[0]   (ggml_concat + ggml_add_inplace, vit.cpp:794-797)
-__global__ void cls_rows_kernel(const float *__restrict__ cls, const float *__restrict__ pos, float *__restrict__ X, int n_img, int N, int D) {
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < D; i += blockDim.x) X[(size_t)b * N * D + i] = cls[i] + pos[i];
-}
-hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_img, int N, int D, hipStream_t stream) {
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(n_img), dim3(256), 0, stream, cls, pos, X, n_img, N, D);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
 // LayerNorm (ggml_norm + ggml_mul + ggml_add_inplace, vit.cpp:808-812, 881-885, 915-919):
 // mean, then biased variance of (x-mean), y = ((x-mean) * 1/sqrt(var+eps)) * w + b, rounded to the
 // operand type of the GEMM that consumes it.  One wave per row, row kept in registers.
@@ -305,37 +263,6 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *X, int n_i
 // bits whichever of the two produced it.  Lane l of the wave holds piece l of each tile (w = l >> 4, j = (l >> 3) & 1, k = l & 7):
 // one fully coalesced 1 KiB load per tile.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT>
-__device__ __forceinline__ void ln_row_tiled(const float *__restrict__ xr, const float *__restrict__ w, const float *__restrict__ b, T *__restrict__ yr, float eps, int lane) {
-    f32x4 v[NT];
-    float mc[LN_MAX_TILES] = {0.0f, 0.0f, 0.0f, 0.0f}, m2[LN_MAX_TILES] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int c = 0; c < NT; ++c) v[c] = *(const f32x4 *)(xr + c * 256 + lane * 4);
-    auto tile_total = [&](float a) {       // a = this lane's piece value -> S_c (uniform)
-        const float s = a + __shfl_xor(a, 8);                      // s(w, k) = a(w, 0, k) + a(w, 1, k)
-        const float p = ln_sum8(s);                                // P(w), the same bits in the 16 lanes of wave column w
-        const float p0 = __shfl(p, 0), p1 = __shfl(p, 16), p2 = __shfl(p, 32), p3 = __shfl(p, 48);
-        return ((p0 + p1) + p2) + p3;
-    };
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        mc[c] = tile_total(ln_piece_sum(v[c])) * (1.0f / 256.0f);
-        m2[c] = tile_total(ln_piece_sq(v[c], mc[c]));
-    }
-    float mean, rstd;
-    ln_combine(mc, m2, NT, NT * 256, eps, mean, rstd);
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-        const int idx = c * 256 + lane * 4;
-        const f32x4 ww = *(const f32x4 *)(w + idx), bb = *(const f32x4 *)(b + idx);
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { float t = (v[c][e] - mean) * rstd; t = t * ww[e]; o[e] = t + bb[e]; }
-        const typename Pair<T>::v2 lo = round_pair<T>(o[0], o[1]), hi = round_pair<T>(o[2], o[3]);
-        *(typename Elem<T>::v4 *)(yr + idx) = typename Elem<T>::v4{lo[0], lo[1], hi[0], hi[1]};
-    }
-}
-
 template <typename T, int VEC, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ w, const float *__restrict__ b,
                                                         T *__restrict__ y, long ldy, int M, float eps, int group, long gstride) {
@@ -1110,6 +1037,7 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16, true>(epi, none, nullptr, true) : launch_gemm_t<__bf16, true>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
+        if (dt == 0 && (e = launch_patch_embed(0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, true)) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_flow<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_flow<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_persist<_Float16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr) : launch_attention_persist<__bf16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr))) != hipSuccess) return e;
         for (int nkt : kAttnNkt) {
@@ -1206,6 +1134,14 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ pro
         if (lane == 0) { out[((size_t)row * k + it) * 2] = bv; ((int *)out)[((size_t)row * k + it) * 2 + 1] = bi; }
         pv = bv; pi = bi;
     }
+}
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+hipError_t launch_spin(int microseconds, hipStream_t stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, (long long)microseconds * 100);
+    return hipGetLastError();
 }
 hipError_t launch_topk(const float *probs, int rows, int cols, int k, void *out_pairs, hipStream_t stream) {
     if (rows <= 0 || cols <= 0 || k <= 0 || k > cols) return hipErrorInvalidValue;
