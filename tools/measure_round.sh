@@ -1,22 +1,29 @@
 #!/bin/bash
 # Round-end measurement batch (run on the GPU box through gpurun):  bash tools/measure_round.sh <tag>
-# bench lines (bf16 / f16 / q4_0 file), rocprofv3 kernel trace + two PMC passes of the same forward (sub-batches serialised).
+# default bench line (carries parity / sustained / f16 mode / configs 3 and 5), rocprofv3 kernel trace + two PMC passes of the same forward
+# with the context's profiling schedule (sub-batches back to back on one stream: "one launch" = what bench.py's profiled step times).
 tag=${1:-rXX}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag; mkdir -p $out
 python bench.py --steps 30 --warmup 10 > $out/bench_bf16.json 2> $out/bench_bf16.err
-python bench.py --steps 30 --warmup 10 --dtype f16 --no-cpu-baseline > $out/bench_f16.json 2> $out/bench_f16.err
-python bench.py --steps 30 --warmup 10 --ftype q4_0 --no-cpu-baseline > $out/bench_q4_0.json 2> $out/bench_q4_0.err
-python bench.py --steps 20 --warmup 5 --model vit_large_patch16_384 --batch 128 --no-cpu-baseline > $out/bench_large384.json 2> $out/bench_large384.err
+python bench.py --steps 30 --warmup 10 --dtype f16 --no-cpu-baseline --no-extras > $out/bench_f16.json 2> $out/bench_f16.err
+python bench.py --steps 30 --warmup 10 --ftype q4_0 --no-extras > $out/bench_q4_0.json 2> $out/bench_q4_0.err
+python bench.py --steps 20 --warmup 5 --model vit_large_patch16_384 --batch 128 --no-cpu-baseline --no-extras > $out/bench_large384.json 2> $out/bench_large384.err
+cat $out/bench_bf16.json $out/bench_f16.json $out/bench_q4_0.json $out/bench_large384.json > $out/bench.jsonl
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 5 bf16 > $R/$out/prof.log 2>&1 )
-( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $R/$out/pmc1 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 > $R/$out/pmc1.log 2>&1 )
-( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $R/$out/pmc2 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 > $R/$out/pmc2.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 5 bf16 profile=1 > $R/$out/prof.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $R/$out/pmc1 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 profile=1 > $R/$out/pmc1.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $R/$out/pmc2 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 profile=1 > $R/$out/pmc2.log 2>&1 )
 python tools/rocpd_summary.py $(find $out/prof $out/pmc1 $out/pmc2 -name "*.db" | sort) > $out/rocprofv3_summary.txt 2>&1
 python tools/hbm_traffic.py $(find $out/pmc1 -name "*.db" | head -1) $(find $out/pmc2 -name "*.db" | head -1) --commit "${COMMIT:-unknown}" --out $out/hbm_traffic.json > $out/hbm_traffic.log 2>&1
-( cd /tmp && VITX_SLICES_SERIAL=1 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/profL -o fwd -- python $R/tools/prof_forward.py vit_large_patch16_384 128 3 bf16 > $R/$out/profL.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/profL -o fwd -- python $R/tools/prof_forward.py vit_large_patch16_384 128 3 bf16 profile=1 > $R/$out/profL.log 2>&1 )
 python tools/rocpd_summary.py $(find $out/profL -name "*.db" | sort) > $out/rocprofv3_summary_large384.txt 2>&1
 # small-batch latency table: f16 file and q4_0 file (blocks in HBM), bf16 compute
 for ft in f16 q4_0; do for b in 1 8 32 64; do TF_FTYPE=$ft python tools/time_fwd.py $b vit_base_patch16_224 bf16 100 2>&1 | grep -v amdgpu; done; done > $out/small_batches.txt
 find $out -name "*.db" -size +20M -delete
-tail -c 600 $out/bench_bf16.json; echo; head -12 $out/rocprofv3_summary.txt
+python - <<PY
+import json
+for l in open("$out/bench.jsonl"):
+    d = json.loads(l); print(d["config"]["workload"][:60], d["value"], d["ms_per_step"], d.get("roofline", {}).get("frac"))
+PY
+head -14 $out/rocprofv3_summary.txt; cat $out/hbm_traffic.json | head -14

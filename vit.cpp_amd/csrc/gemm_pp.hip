@@ -240,25 +240,35 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
         const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(ln.out, 0, (int)0xffffffffu, 0x00020000);
         // ln.out is [M][N] of T with the GEMM's row length: the X offsets halve (f32 -> 16 bit)
         const int uoff = voff >> 1, usoff = soff >> 1, usoff8 = soff8 >> 1;
+        // A lane holds columns 4 lk .. + 3 of BOTH 32-column halves; neighbouring lanes (lk ^ 1) swap one half so that the even lane owns 8
+        // consecutive columns of half 0 and the odd lane 8 of half 1: ONE 16-byte store per lane and row, whole 128-byte lines per
+        // instruction (8 rows), instead of two 8-byte stores to half lines.
+        const bool odd = lk & 1;
+        const int ucol = odd ? 64 + (lk - 1) * 8 : lk * 8;          // byte offset inside the wave's 128-byte row segment
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const f32x2 mr = *(const f32x2 *)(fin + (wr * 128 + b * 16 + t * 8 + lr) * 2);
+                unsigned pk[2][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { float v = (xv(b, j, t)[e] - mr[0]) * mr[1]; v = v * gw[j][e]; o[e] = v + gb[j][e]; }
-                    const typename Pair<T>::v2 lo = round_pair<T>(o[0], o[1]), hi = round_pair<T>(o[2], o[3]);
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, ru, uoff + j * 64, usoff + (b * 2 + t) * usoff8, 0);
+                    pk[j][0] = __builtin_bit_cast(unsigned, round_pair<T>(o[0], o[1])); pk[j][1] = __builtin_bit_cast(unsigned, round_pair<T>(o[2], o[3]));
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                // give away the half this lane does not store, take the neighbour's piece of the half it does
+                const unsigned g0 = odd ? pk[0][0] : pk[1][0], g1 = odd ? pk[0][1] : pk[1][1];
+                const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)g0, 0xB1, 0xf, 0xf, true), r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)g1, 0xB1, 0xf, 0xf, true);      // quad_perm [1, 0, 3, 2]
+                const u32x4 d = odd ? u32x4{r0, r1, pk[1][0], pk[1][1]} : u32x4{pk[0][0], pk[0][1], r0, r1};
+                __builtin_amdgcn_raw_buffer_store_b128(d, ru, uoff - lk * 8 + ucol, usoff + (b * 2 + t) * usoff8, 0);
+                __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 1" ::: "memory"); __builtin_amdgcn_sched_barrier(0);       // pp_store_b128's wait states
             }
     }
     store_x();
     lds_barrier();         // the statistics area (and `fail`) is re-used by the next tile, and the ring slot is re-staged soon after
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // the 32 normalised-row stores are older and have landed; at most the 32 X stores stay in flight
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // the 16 normalised-row stores are older and have landed; at most the 32 X stores stay in flight
     return true;
 #undef xv
 }
