@@ -17,7 +17,24 @@
 #define P4 "v_pk_fma_f32 v[52:53], v[52:53], v[54:55], v[56:57]\nv_pk_fma_f32 v[54:55], v[54:55], v[56:57], v[58:59]\nv_pk_fma_f32 v[56:57], v[56:57], v[58:59], v[60:61]\nv_pk_fma_f32 v[58:59], v[58:59], v[60:61], v[62:63]\n"
 #define D4 "v_dot2c_f32_bf16 v60, v52, v53\nv_dot2c_f32_bf16 v61, v54, v55\nv_dot2c_f32_bf16 v62, v56, v57\nv_dot2c_f32_bf16 v63, v58, v59\n"
 
+#define K8 "v_fmamk_f32 v40, v40, 0x3e38aa3b, v48\nv_fmamk_f32 v41, v41, 0x3e38aa3b, v48\nv_fmamk_f32 v42, v42, 0x3e38aa3b, v48\nv_fmamk_f32 v43, v43, 0x3e38aa3b, v48\nv_fmamk_f32 v44, v44, 0x3e38aa3b, v48\nv_fmamk_f32 v45, v45, 0x3e38aa3b, v48\nv_fmamk_f32 v46, v46, 0x3e38aa3b, v48\nv_fmamk_f32 v47, v47, 0x3e38aa3b, v48\n"
+#define A4 "v_pk_add_f32 v[40:41], v[40:41], v[48:49]\nv_pk_add_f32 v[42:43], v[42:43], v[48:49]\nv_pk_add_f32 v[44:45], v[44:45], v[48:49]\nv_pk_add_f32 v[46:47], v[46:47], v[48:49]\n"
+#define X4 "v_max3_f32 v40, v40, v50, v51\nv_max3_f32 v41, v41, v52, v53\nv_max3_f32 v42, v42, v54, v55\nv_max3_f32 v43, v43, v56, v57\n"
+#define E8 "v_exp_f32 v40, v40\nv_exp_f32 v41, v41\nv_exp_f32 v42, v42\nv_exp_f32 v43, v43\nv_exp_f32 v44, v44\nv_exp_f32 v45, v45\nv_exp_f32 v46, v46\nv_exp_f32 v47, v47\n"
+#define H8 "v_exp_f16 v40, v40\nv_exp_f16 v41, v41\nv_exp_f16 v42, v42\nv_exp_f16 v43, v43\nv_exp_f16 v44, v44\nv_exp_f16 v45, v45\nv_exp_f16 v46, v46\nv_exp_f16 v47, v47\n"
+#define C4B "v_cvt_pk_bf16_f32 v52, v40, v41\nv_cvt_pk_bf16_f32 v53, v42, v43\nv_cvt_pk_bf16_f32 v54, v44, v45\nv_cvt_pk_bf16_f32 v55, v46, v47\n"
+#define D2 "v_dot2c_f32_bf16 v60, v52, v53\nv_dot2c_f32_bf16 v61, v54, v55\n"
 template <int MODE> __device__ __forceinline__ void body() {
+    if constexpr (MODE == 12) asm volatile(K8 K8 K8 K8 ::: CLOB);                                  // 32 v_fmamk
+    if constexpr (MODE == 13) asm volatile(A4 A4 A4 A4 ::: CLOB);                                  // 16 v_pk_add_f32 (32 elements)
+    if constexpr (MODE == 14) asm volatile(X4 X4 X4 X4 ::: CLOB);                                  // 16 v_max3
+    if constexpr (MODE == 15) asm volatile(E8 E8 ::: CLOB);                                        // 16 v_exp_f32, 8 registers (dependent at distance 8)
+    if constexpr (MODE == 16) asm volatile(H8 H8 ::: CLOB);                                        // 16 v_exp_f16
+    if constexpr (MODE == 17) asm volatile(K8 E8 C4B D2 K8 E8 C4B D2 ::: CLOB);                    // softmax body for 16 scores: fmamk, exp, cvt, dot2c
+    if constexpr (MODE == 18) asm volatile(A4 E8 C4B D2 A4 E8 C4B D2 ::: CLOB);                    // the same with packed adds
+    if constexpr (MODE == 19) asm volatile(C4B C4B C4B C4B ::: CLOB);                              // 16 cvt_pk
+    if constexpr (MODE == 20) asm volatile(D2 D2 D2 D2 D2 D2 D2 D2 ::: CLOB);                      // 16 dot2c (2 chains)
+
     if constexpr (MODE == 0) asm volatile(M0 M1 M2 M3 ::: CLOB);                                   // 4 independent MFMAs
     if constexpr (MODE == 1) asm volatile(M0 F8 M1 F8 M2 F8 M3 F8 ::: CLOB);                       // interleaved with 32 v_fma
     if constexpr (MODE == 2) asm volatile(F8 F8 F8 F8 ::: CLOB);                                   // 32 v_fma alone
@@ -75,6 +92,20 @@ int main() {
     run<10, 10>("16 cvt_pk + 16 pk_fma + 16 dot2c", 4, 4);
     run<9, 9>("4 MFMA interleaved with 16 cvt_pk + 16 pk_fma + 16 dot2c", 4, 4);
     run<11, 11>("dependent MFMA pairs + 32 v_fma", 4, 4);
+    run<12, 12>("32 v_fmamk", 4, 4);
+    run<13, 13>("16 v_pk_add_f32", 4, 4);
+    run<14, 14>("16 v_max3", 4, 4);
+    run<15, 15>("16 v_exp_f32 (8 regs)", 4, 4);
+    run<16, 16>("16 v_exp_f16", 4, 4);
+    run<19, 19>("16 cvt_pk_bf16", 4, 4);
+    run<20, 20>("16 dot2c (2 chains)", 4, 4);
+    run<17, 17>("softmax body, 16 scores: 16 fmamk 16 exp 8 cvt 4 dot2c", 4, 4);
+    run<18, 18>("softmax body, 16 scores: 8 pk_add 16 exp 8 cvt 4 dot2c", 4, 4);
+    run<17, 17>("2 waves/SIMD both: softmax body (fmamk)", 8, 8);
+    run<18, 18>("2 waves/SIMD both: softmax body (pk_add)", 8, 8);
+    run<12, 12>("2 waves/SIMD both: 32 v_fmamk", 8, 8);
+    run<15, 15>("2 waves/SIMD both: 16 v_exp_f32", 8, 8);
+    run<0, 17>("A: 4 MFMA   B: softmax body", 8, 4);
     printf("-- two waves per SIMD, different mixes (A = waves 0-3, B = waves 4-7)\n");
     run<0, 2>("A: 4 MFMA   B: 32 v_fma", 8, 4);
     run<0, 4>("A: 4 MFMA   B: 16 v_exp", 8, 4);

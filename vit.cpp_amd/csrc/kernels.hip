@@ -800,12 +800,16 @@ static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, i
 // exp follows AttnExp<T> (device_common.h): F16 = ggml_soft_max's table semantics, BF16 = one f32 exp2 per key.
 // Keys 197..223 read the next image's rows (finite; masked to -inf) or the zeros a buffer load returns out of range.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NKT>
-__global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// QT = 16-query tiles this wave computes (0: the eighth wave, which only moves data; 1: the wave whose second tile holds no real query;
+// 2), NT16V = 16-key tiles that hold a real key (13 for 193..208 tokens, 14 above): both compile-time, so an item's work is ONE basic
+// block -- with run-time tile tests (r03 first build) every tile was its own block and paid its LDS latency alone: read, wait, 4 MFMAs.
+// FLAGS: 0 in the product; ablation builds under -DVITX_LAB only (tools/attn_bench.py, garbage results by design): 1 = no softmax
+// arithmetic, 2 = no K / V DMA after the first item, 4 = no output stores, 8 = no QK^T products, 16 = no PV products, 32 = no Q loads.
+template <typename T, int NKT, int NT16V, int QT, int FLAGS>
+__device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv, T *__restrict__ out, char *smem, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
     constexpr int NK = NKT * 32, KB = NK * 128, BUF = 2 * KB;       // one item: K image + V image
     constexpr int PIECES = NK * 8, OPS = (PIECES + 511) / 512;      // 16-byte pieces per image, DMA instructions per thread and image
-    constexpr int NT16 = NKT * 2;                                   // 16-key tiles
+    constexpr int NQ = QT > 0 ? QT : 1;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef typename Elem<T>::v8 v8;
@@ -813,13 +817,9 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__re
     typedef short s4 __attribute__((ext_vector_type(4)));
     typedef short s8 __attribute__((ext_vector_type(8)));
     const int row_bytes = 3 * D * 2;
-    const bool qwave = wave < NKT;
-    const bool two = wave * 32 + 16 < N;        // the wave's second 16-query tile holds at least one real query
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)qkv, 0, (int)total_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)out_bytes, 0x00020000);
-    // (array bounds are a literal on purpose: hipcc drops the HOST stub of a template kernel -- no diagnostic, an undefined symbol at load
-    // time -- when a lambda captures an array whose bound is a value-dependent constexpr local)
     static_assert(OPS <= 4, "at most 256 keys");
     auto item_base = [&](int item) { const int b = item / H, h = item - b * H; return (int)(((size_t)b * N * 3 * D + h * 64) * 2); };     // bytes (< 4 GiB: launcher)
     // DMA piece it * 512 + tid of an image is image row (64 it + row of piece tid), same 16-byte slot: ONE per-lane offset per image and an
@@ -843,11 +843,11 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__re
         }
     };
     // Q fragments (B operand of S^T = K . Q^T): lane (l15 = query of the tile, g4) holds dims k2 * 32 + g4 * 8 .. + 7
-    v8 qf[2][2];
+    v8 qf[NQ][2];
     auto load_q = [&](int item) {
         const T *base = qkv + (size_t)item_base(item) / 2;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             const int qrow = min(wave * 32 + qt * 16 + l15, N - 1);
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) qf[qt][k2] = *(const v8 *)(base + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8);
@@ -867,134 +867,220 @@ __global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__re
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char *)smem);
 
     int item = blockIdx.x;
-    if (item >= items) return;
     int cur_off = 0;
     stage(item, smem);
-    if (qwave) load_q(item);
+    if constexpr (QT > 0) load_q(item);
     __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
 
     for (; item < items; item += gridDim.x) {
-        const char *cur = smem + cur_off;
         const int b = item / H, h = item - b * H;
         const int nitem = item + gridDim.x;
-        f32x4 s[14][2];
-        static_assert(NT16 == 14, "literal array bound above");
-        if (qwave) {
-            // S^T tiles: rows = keys, cols = queries
+        f32x4 s[14][NQ];
+        static_assert(NKT == 7 && (NT16V == 13 || NT16V == 14), "literal array bounds");
+        unsigned long long stamp[6];
+#define VITX_STAMP(I) if (FLAGS & 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[I]) :: "memory");
+        VITX_STAMP(0)
+        if constexpr (QT > 0) {
+            // S^T tiles: rows = keys, cols = queries; a tile of padded keys only (t >= NT16V) is never multiplied.  The K fragments of
+            // tile t + KD are requested before the products of tile t (inline asm + counted lgkmcnt, as for V below: left to itself hipcc
+            // requests a tile right before its products, and all seven waves then sit in that LDS latency together after the barrier)
+            constexpr int KD = 4, KS = KD + 1;
+            typedef int i4 __attribute__((ext_vector_type(4)));
+            i4 kf[KS][2];
+            unsigned ka[2][2];
 #pragma unroll
-            for (int t = 0; t < NT16; ++t) {
-                if (t * 16 < N) {                   // wave-uniform: a tile of padded keys only is never multiplied
-                    const v8 k0 = *(const v8 *)(cur + krd[t & 1][0] + (t >> 1) * 4096), k1 = *(const v8 *)(cur + krd[t & 1][1] + (t >> 1) * 4096);
+            for (int pz = 0; pz < 2; ++pz)
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt) {
-                        if (qt == 0 || two) {
-                            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                            acc = Elem<T>::mfma16(k0, qf[qt][0], acc);
-                            s[t][qt] = Elem<T>::mfma16(k1, qf[qt][1], acc);
-                        }
-                    }
+                for (int k2 = 0; k2 < 2; ++k2) ka[pz][k2] = lds0 + (unsigned)cur_off + krd[pz][k2];
+            auto read_k = [&](int t) {
+                const int sl = t % KS;
+                switch (t >> 1) {       // the immediate offset must be a literal
+#define VITX_RK(I) case I: asm volatile("ds_read_b128 %0, %1 offset:" #I "*4096" : "=v"(kf[sl][0]) : "v"(ka[t & 1][0])); asm volatile("ds_read_b128 %0, %1 offset:" #I "*4096" : "=v"(kf[sl][1]) : "v"(ka[t & 1][1])); break;
+                VITX_RK(0) VITX_RK(1) VITX_RK(2) VITX_RK(3) VITX_RK(4) VITX_RK(5) VITX_RK(6)
+#undef VITX_RK
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < KD; ++t) read_k(t);
+#pragma unroll
+            for (int t = 0; t < NT16V; ++t) {
+                const int sl = t % KS;
+                if (t + KD < NT16V) read_k(t + KD);
+                const int behind = 2 * ((t + KD < NT16V ? t + KD : NT16V - 1) - t);        // reads requested after tile t's
+                switch (behind) {
+#define VITX_WK(C) case C: asm volatile("s_waitcnt lgkmcnt(" #C ")" : "+v"(kf[sl][0]), "+v"(kf[sl][1])); break;
+                VITX_WK(0) VITX_WK(2) VITX_WK(4) VITX_WK(6) VITX_WK(8)
+#undef VITX_WK
+                }
+                const v8 k0 = __builtin_bit_cast(v8, kf[sl][0]), k1 = __builtin_bit_cast(v8, kf[sl][1]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (FLAGS & 8) { s[t][qt] = f32x4{k0[0], k1[1], k0[2], k1[3]}; continue; }
+                    acc = Elem<T>::mfma16(k0, qf[qt][0], acc);
+                    s[t][qt] = Elem<T>::mfma16(k1, qf[qt][1], acc);
                 }
             }
         }
+        VITX_STAMP(1)
         __builtin_amdgcn_sched_barrier(0);
-        if (nitem < items) stage(nitem, smem + (cur_off ^ BUF));      // lands during the softmax and the PV products
+        // (issued at the top of the item instead -- the buffer is free since the barrier -- the DMA costs 1.8 us per 128-image launch:
+        // it then lands while all seven waves read K fragments)
+        if (nitem < items && !(FLAGS & 2)) stage(nitem, smem + (cur_off ^ BUF));      // lands during the softmax and the PV products
         __builtin_amdgcn_sched_barrier(0);
-        if (qwave) {
-            v8 p[7][2];
-            float inv[2] = {0.0f, 0.0f};
-            static_assert(NKT == 7, "literal array bound above");
+        if constexpr (QT > 0) {
+            v8 p[7][NQ];
+            float inv[NQ];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                if (qt == 0 || two) {
-                    float mxs = -INFINITY;
+            for (int qt = 0; qt < QT; ++qt) {
+                if (FLAGS & 1) {
 #pragma unroll
-                    for (int t = 0; t < NT16; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (t >= 12) {       // only the last two 16-key tiles can hold padded keys (N > 192)
-                                const int key = t * 16 + 4 * g4 + r;
-                                if (key >= N) s[t][qt][r] = -INFINITY;
-                            }
-                            mxs = fmaxf(mxs, s[t][qt][r]);
-                        }
-                    mxs = fmaxf(mxs, __shfl_xor(mxs, 16));
-                    mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
-                    const float nmx = -AttnExp<T>::kScale * mxs;
-                    float sum = 0.0f;
-#pragma unroll
-                    for (int ks = 0; ks < NKT; ++ks) {      // numerators per AttnExp<T>; row sum of the ROUNDED values (they are what the PV product sees)
-                        const v2 e0 = AttnExp<T>::pair(s[2 * ks][qt][0], s[2 * ks][qt][1], nmx), e1 = AttnExp<T>::pair(s[2 * ks][qt][2], s[2 * ks][qt][3], nmx);
-                        const v2 e2 = AttnExp<T>::pair(s[2 * ks + 1][qt][0], s[2 * ks + 1][qt][1], nmx), e3 = AttnExp<T>::pair(s[2 * ks + 1][qt][2], s[2 * ks + 1][qt][3], nmx);
-                        sum = Pair<T>::sum2(e0, sum); sum = Pair<T>::sum2(e1, sum); sum = Pair<T>::sum2(e2, sum); sum = Pair<T>::sum2(e3, sum);
+                    for (int ks = 0; ks < NKT; ++ks) {
+                        const f32x4 a = s[2 * ks][qt], c = s[2 * ks + 1 < NT16V ? 2 * ks + 1 : 0][qt];
+                        const v2 e0 = round_pair<T>(a[0], a[1]), e1 = round_pair<T>(a[2], a[3]), e2 = round_pair<T>(c[0], c[1]), e3 = round_pair<T>(c[2], c[3]);
                         p[ks][qt] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
                     }
-                    sum += __shfl_xor(sum, 16);
-                    sum += __shfl_xor(sum, 32);
-                    inv[qt] = 1.0f / sum;
+                    inv[qt] = 1.0f;
+                    continue;
                 }
+                float mxs = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < NT16V; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (t >= 12) {       // only the last two 16-key tiles can hold padded keys (N > 192)
+                            const int key = t * 16 + 4 * g4 + r;
+                            if (key >= N) s[t][qt][r] = -INFINITY;
+                        }
+                        mxs = fmaxf(mxs, s[t][qt][r]);
+                    }
+                mxs = fmaxf(mxs, __shfl_xor(mxs, 16));
+                mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+                const float nmx = -AttnExp<T>::kScale * mxs;
+                float sum = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < NKT; ++ks) {      // numerators per AttnExp<T>; row sum of the ROUNDED values (they are what the PV product sees)
+                    const v2 e0 = AttnExp<T>::pair(s[2 * ks][qt][0], s[2 * ks][qt][1], nmx), e1 = AttnExp<T>::pair(s[2 * ks][qt][2], s[2 * ks][qt][3], nmx);
+                    sum = Pair<T>::sum2(e0, sum); sum = Pair<T>::sum2(e1, sum);
+                    v2 e2 = __builtin_bit_cast(v2, 0u), e3 = __builtin_bit_cast(v2, 0u);       // a tile of padded keys: probability 0
+                    if (2 * ks + 1 < NT16V) {
+                        e2 = AttnExp<T>::pair(s[2 * ks + 1][qt][0], s[2 * ks + 1][qt][1], nmx); e3 = AttnExp<T>::pair(s[2 * ks + 1][qt][2], s[2 * ks + 1][qt][3], nmx);
+                        sum = Pair<T>::sum2(e2, sum); sum = Pair<T>::sum2(e3, sum);
+                    }
+                    p[ks][qt] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                inv[qt] = 1.0f / sum;
             }
+            VITX_STAMP(2)
             // the next item's Q fragments: issued here (after the scores died: 16 registers the softmax needs) and in flight under the PV products
             __builtin_amdgcn_sched_barrier(0);
-            if (nitem < items) load_q(nitem);
+            if (nitem < items && !(FLAGS & 32)) load_q(nitem);
             __builtin_amdgcn_sched_barrier(0);
             // O^T = V^T . P^T: rows = head dims (4 tiles of 16), cols = queries; V^T fragments by transposed LDS reads (inline asm: behind the
-            // builtin hipcc waits vmcnt(0) in front of every transposed read while the next item's LDS-DMA is in flight)
-            f32x4 o[4][2];
+            // builtin hipcc waits vmcnt(0) in front of every transposed read while the next item's LDS-DMA is in flight), the reads of key step
+            // ks + 1 issued ahead of the products of step ks (LDS operations return in order: lgkmcnt(8) = the older eight have landed)
+            f32x4 o[4][NQ];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) o[dt][qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int ks = 0; ks < NKT; ++ks) {
+                for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            s4 f[2][4][2];
+            auto read_v = [&](int ks) {
                 const unsigned cb = lds0 + (unsigned)cur_off + ks * 4096;
-                s4 f[4][2];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const unsigned va = cb + vrd[dt];
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[dt][0]) : "v"(va));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[dt][1]) : "v"(va));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[ks & 1][dt][0]) : "v"(va));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[ks & 1][dt][1]) : "v"(va));
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]),
-                                                      "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]));
+            };
+            read_v(0);
+#pragma unroll
+            for (int ks = 0; ks < NKT; ++ks) {
+                const int c = ks & 1;
+                if (ks + 1 < NKT) {
+                    read_v(ks + 1);
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
+                                                          "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
+                                                          "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
+                }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const s8 both = __builtin_shufflevector(f[dt][0], f[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s8 both = __builtin_shufflevector(f[c][dt][0], f[c][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-                        if (qt == 0 || two) o[dt][qt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p[ks][qt], o[dt][qt]);
+                    for (int qt = 0; qt < QT; ++qt) {
+                        if (FLAGS & 16) { o[dt][qt][0] += (float)both[0] + (float)p[ks][qt][dt]; continue; }
+                        o[dt][qt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p[ks][qt], o[dt][qt]);
+                    }
                 }
             }
+            VITX_STAMP(3)
             // lane (l15 = query, g4) holds O[query][dt * 16 + 4 g4 .. + 3]: 8 bytes per (dt, qt); rows past N go out of the buffer's range and
-            // are dropped, so every computing wave issues exactly 8 stores per item (the counted wait below relies on it)
+            // are dropped, so a wave issues exactly 4 QT stores per item (the counted wait below relies on it)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {             // also for a second tile without real queries (zeros, all dropped): a uniform store count
+            for (int qt = 0; qt < QT; ++qt) {
                 const int qrow = wave * 32 + qt * 16 + l15;
                 const unsigned off = qrow < N ? (unsigned)((((size_t)b * N + qrow) * D + h * 64 + g4 * 4) * 2) : 0xfffffff0u;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const v2 lo = round_pair<T>(o[dt][qt][0] * inv[qt], o[dt][qt][1] * inv[qt]), hi = round_pair<T>(o[dt][qt][2] * inv[qt], o[dt][qt][3] * inv[qt]);
                     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    if (FLAGS & 4) { if (lo[0] == (T)123.0f && hi[1] == (T)77.0f) out[off] = lo[1]; continue; }       // keeps the values alive, never true
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, rsrc_o, (int)(off + (qrow < N ? dt * 32 : 0)), 0, 0);
                 }
             }
         }
-        // The next item's K / V and Q must have landed; this wave's 8 output stores are YOUNGER than those loads and may stay in flight
+        // The next item's K / V and Q must have landed; this wave's output stores are YOUNGER than those loads and may stay in flight
         // (vector-memory operations retire in issue order on gfx9: the counted wait skips exactly the stores, as gemm_pp.hip does).
-        if (qwave) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VITX_STAMP(4)
+        if constexpr (QT == 2 && !(FLAGS & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (QT == 1 && !(FLAGS & 4)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VITX_STAMP(5)
+        if ((FLAGS & 64) && blockIdx.x == 0 && lane == 0 && item / (int)gridDim.x < 6) {       // lab: [wave][item][6] shader-clock stamps behind the output rows
+            unsigned long long *dbg = (unsigned long long *)((char *)out + out_bytes) + (wave * 6 + item / gridDim.x) * 6;
+            for (int i = 0; i < 6; ++i) dbg[i] = (QT == 0 && i >= 1 && i <= 3) ? stamp[0] : stamp[i];
+        }
+#undef VITX_STAMP
         __builtin_amdgcn_s_barrier();             // every wave is done with this item's buffer; the next one is visible to all
-        cur_off ^= BUF;
+        if (!(FLAGS & 2)) cur_off ^= BUF;
     }
 }
+
+template <typename T, int NKT, int NT16V, int FLAGS = 0>
+__global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= items) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // every wave runs the same number of items and barriers, whichever build of the loop it takes
+    if (wave >= NKT) attention_persist_loop<T, NKT, NT16V, 0, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
+    else if (wave * 32 + 16 < NT16V * 16) attention_persist_loop<T, NKT, NT16V, 2, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
+    else attention_persist_loop<T, NKT, NT16V, 1, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
+}
 template <typename T>
-static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img, int N, int D, int H, int n_cu, hipStream_t stream) {
+static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img, int N, int D, int H, int n_cu, hipStream_t stream, int flags = 0) {
     constexpr int NKT = 7, lds = 2 * 2 * NKT * 32 * 128;          // two items x (K + V) x 224 rows x 128 B = 112 KiB
-    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
+    if (n_img == 0) {       // device bring-up
+        hipError_t e = hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
     const size_t total = (size_t)n_img * N * 3 * D * 2;
     if (total >= 0xf0000000u) return hipErrorInvalidValue;          // 32-bit buffer offsets
     const int items = n_img * H;
     const int grid = items < n_cu ? items : n_cu;
-    hipLaunchKernelGGL((attention_persist_kernel<T, NKT>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
+#ifdef VITX_LAB
+#define VITX_PERSIST_LAB(F) case F: { static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT, 13, F>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
+        hipLaunchKernelGGL((attention_persist_kernel<T, NKT, 13, F>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3)); return hipGetLastError(); }
+    if (flags && N <= 208) switch (flags) { VITX_PERSIST_LAB(1) VITX_PERSIST_LAB(2) VITX_PERSIST_LAB(4) VITX_PERSIST_LAB(8) VITX_PERSIST_LAB(16) VITX_PERSIST_LAB(32) VITX_PERSIST_LAB(25) VITX_PERSIST_LAB(38) VITX_PERSIST_LAB(63) VITX_PERSIST_LAB(64) default: return hipErrorInvalidValue; }
+#undef VITX_PERSIST_LAB
+#endif
+    if (N <= 208) hipLaunchKernelGGL((attention_persist_kernel<T, NKT, 13>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
+    else hipLaunchKernelGGL((attention_persist_kernel<T, NKT, 14>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
     return hipGetLastError();
 }
 bool attention_persist_supports(int n_img, int N, int D) { return N > 192 && N <= 224 && (size_t)n_img * N * 3 * D * 2 < 0xf0000000u; }
@@ -1016,7 +1102,7 @@ hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *o
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
     // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax)
     if ((t.attn_kernel == ATTN_PERSIST || t.attn_kernel == ATTN_AUTO) && attention_persist_supports(n_img, N, D))
-        return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.n_cu, stream) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.n_cu, stream);
+        return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.n_cu, stream, t.attn_flags) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.n_cu, stream, t.attn_flags);
     if (t.attn_kernel == ATTN_PERSIST) return hipErrorInvalidValue;
     const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_kernel == ATTN_SINGLE);
     if (t.attn_kernel == ATTN_FLOW || !single)
@@ -1070,7 +1156,6 @@ const Tuning *tuning_for_device(int device) {
     t->pp_flags = env_int("VITX_PP_FLAGS", 0);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_kernel = env_int("VITX_ATTN_KERNEL", 0);
-    t->ln_fuse = env_int("VITX_LN_FUSE", 1);
 #endif
     const hipError_t e = prepare_device_kernels(*t);
     if (cur != device) (void)hipSetDevice(cur);
