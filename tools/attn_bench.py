@@ -13,7 +13,7 @@ bf = len(sys.argv) > 5 and sys.argv[5] == "bf16"
 dt = torch.bfloat16 if bf else torch.float16
 DT = B.BF16 if bf else B.F16
 qkv = (torch.randn((n_img * N, 3 * D), device="cuda") * 0.8).to(dt)
-out_all = torch.zeros((n_img * N + 8, D), device="cuda", dtype=dt)       # + room for the lab build's clock stamps
+out_all = torch.zeros((n_img * N + 16, D), device="cuda", dtype=dt)       # + room for the lab build's clock stamps
 out = out_all[:n_img * N]
 L = B.lib(); s = torch.cuda.current_stream().cuda_stream
 for _ in range(3): B.check(L.vitx_op_attention_ex(DT, kern, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, s))
@@ -38,10 +38,11 @@ if kern not in (1,) and kern < 16:      # bit-compare with the single-pass kerne
 
 if kern >= 16 and (kern >> 4) & 64:      # lab build: per-phase shader-clock stamps of workgroup 0, [wave][item][6]
     torch.cuda.synchronize()
-    st = out_all[n_img * N:].view(torch.int64).flatten()[:8 * 6 * 6].view(8, 6, 6).cpu()
+    NW = 16
+    st = out_all[n_img * N:].view(torch.int64).flatten()[:NW * 6 * 6].view(NW, 6, 6).cpu()
     t00 = int(st[0, 0, 0])
     names = ["QK^T", "softmax", "PV", "stores+wait", "barrier"]
-    for w in range(8):
-        for it in range(1, 5):
+    for w in range(NW):
+        for it in range(2, 4):
             d = [int(st[w, it, i + 1] - st[w, it, i]) for i in range(5)]
             print(f"wave {w} item {it}: start {int(st[w, it, 0]) - t00:7d}  " + "  ".join(f"{n} {x:5d}" for n, x in zip(names, d)) + f"   item {int(st[w, it, 5] - st[w, it, 0])}")

@@ -74,7 +74,8 @@ static void run(const char *what, int waves, int split) {
     if (e != hipSuccess) { printf("%s: %s\n", what, hipGetErrorString(e)); fflush(stdout); return; }
     long h[64]; (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     // s_memtime ticks at 100 MHz on gfx950?  report raw ticks per iteration for wave 0 and the first wave of the second group
-    printf("%-64s waves %2d: A %.1f", what, waves, (double)h[0] / iters);
+    long mx = 0; for (int w = 0; w < waves; ++w) mx = h[w] > mx ? h[w] : mx;        // the slowest wave: what the SIMD needed for all of them
+    printf("%-64s waves %2d: A %.1f (slowest wave %.1f)", what, waves, (double)h[0] / iters, (double)mx / iters);
     if (split < waves) printf("   B %.1f", (double)h[split] / iters);
     printf("   (ticks/iter)\n"); fflush(stdout);
     (void)hipFree(d);
@@ -106,6 +107,13 @@ int main() {
     run<12, 12>("2 waves/SIMD both: 32 v_fmamk", 8, 8);
     run<15, 15>("2 waves/SIMD both: 16 v_exp_f32", 8, 8);
     run<0, 17>("A: 4 MFMA   B: softmax body", 8, 4);
+    run<12, 12>("4 waves/SIMD all: 32 v_fmamk", 16, 16);
+    run<15, 15>("4 waves/SIMD all: 16 v_exp_f32", 16, 16);
+    run<17, 17>("4 waves/SIMD all: softmax body (fmamk)", 16, 16);
+    run<18, 18>("4 waves/SIMD all: softmax body (pk_add)", 16, 16);
+    run<14, 14>("4 waves/SIMD all: 16 v_max3", 16, 16);
+    run<19, 19>("4 waves/SIMD all: 16 cvt_pk", 16, 16);
+    run<0, 0>("4 waves/SIMD all: 4 MFMA 32x32x16", 16, 16);
     printf("-- two waves per SIMD, different mixes (A = waves 0-3, B = waves 4-7)\n");
     run<0, 2>("A: 4 MFMA   B: 32 v_fma", 8, 4);
     run<0, 4>("A: 4 MFMA   B: 16 v_exp", 8, 4);

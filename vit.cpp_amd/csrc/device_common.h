@@ -19,11 +19,15 @@ template <> struct Elem<_Float16> {
     typedef half8 v8; typedef half4 v4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    typedef short bits4 __attribute__((ext_vector_type(4)));      // half the k-slots of mfma16: lane group g holds k = 4 g .. 4 g + 3
+    static __device__ __forceinline__ f32x4 mfma16k16(bits4 a, bits4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(v4, a), __builtin_bit_cast(v4, b), c, 0, 0, 0); }
 };
 template <> struct Elem<__bf16> {
     typedef bf16x8 v8; typedef bf16x4 v4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    typedef short bits4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 mfma16k16(bits4 a, bits4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 };
 template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)(T)x; }   // round-trip through the operand type
 
@@ -85,7 +89,8 @@ template <typename T> struct AttnExp;
 template <> struct AttnExp<_Float16> {
     static constexpr float kScale = 0.125f;
     static __device__ __forceinline__ Pair<_Float16>::v2 pair(float s0, float s1, float nmx) {
-        const Pair<_Float16>::v2 dh = round_pair<_Float16>(__builtin_fmaf(s0, 0.125f, nmx), __builtin_fmaf(s1, 0.125f, nmx));
+        const f32x2 d = __builtin_elementwise_fma(f32x2{s0, s1}, f32x2{0.125f, 0.125f}, f32x2{nmx, nmx});       // one v_pk_fma_f32: same bits as two fmaf
+        const Pair<_Float16>::v2 dh = round_pair<_Float16>(d[0], d[1]);
         const f32x2 t = f32x2{(float)dh[0], (float)dh[1]} * f32x2{1.44269504f, 1.44269504f};
         return round_pair<_Float16>(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
     }
@@ -93,9 +98,36 @@ template <> struct AttnExp<_Float16> {
 template <> struct AttnExp<__bf16> {
     static constexpr float kScale = 0.125f * 1.44269504088896340736f;
     static __device__ __forceinline__ Pair<__bf16>::v2 pair(float s0, float s1, float nmx) {
-        return round_pair<__bf16>(__builtin_amdgcn_exp2f(__builtin_fmaf(s0, kScale, nmx)), __builtin_amdgcn_exp2f(__builtin_fmaf(s1, kScale, nmx)));
+        const f32x2 d = __builtin_elementwise_fma(f32x2{s0, s1}, f32x2{kScale, kScale}, f32x2{nmx, nmx});        // one v_pk_fma_f32: same bits as two fmaf
+        return round_pair<__bf16>(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
     }
 };
+
+// Reductions over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48) without the LDS crossbar: v_permlane16_swap /
+// v_permlane32_swap (gfx950) exchange rows in the VALU -- no ds_bpermute, no lgkmcnt wait in the middle of a dependent chain.
+// swap16(x, x) leaves {row 0, row 0, row 2, row 2} and {row 1, row 1, row 3, row 3}; swap32 of the result {lower half, lower half} and
+// {upper half, upper half}: after both steps every lane holds the combination of all four rows.
+// (elements are copied out before the bit cast: __builtin_bit_cast applied to a[1] of the returned vector reads element 0 -- hipcc 7.2)
+__device__ __forceinline__ void rows_swap16(float x, float &u, float &v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    u = __builtin_bit_cast(float, a0); v = __builtin_bit_cast(float, a1);
+}
+__device__ __forceinline__ void rows_swap32(float x, float &u, float &v) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned a0 = a[0], a1 = a[1];
+    u = __builtin_bit_cast(float, a0); v = __builtin_bit_cast(float, a1);
+}
+__device__ __forceinline__ float rows4_max(float x) {
+    float u, v;
+    rows_swap16(x, u, v); x = fmaxf(u, v);
+    rows_swap32(x, u, v); return fmaxf(u, v);
+}
+__device__ __forceinline__ float rows4_sum(float x) {       // (row 0 + row 1) + (row 2 + row 3) in every lane: the same bits everywhere
+    float u, v;
+    rows_swap16(x, u, v); x = u + v;
+    rows_swap32(x, u, v); return u + v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm statistics by 256-column tiles (ggml_norm, /root/reference/vit.cpp:808-812, 881-885): the ONE definition both the

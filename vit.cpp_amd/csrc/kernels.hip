@@ -784,74 +784,82 @@ static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, i
 
 // ------------------------------------------------------------------------------------------------
 // Persistent single-pass attention (vit.cpp:826-866) for 193..224 tokens -- ViT-*/16 at 224^2, the headline configuration.
-//   * one persistent workgroup per CU, 8 waves, walks (image, head) items; wave w owns queries 32 w .. 32 w + 31 of the item (7 waves
-//     compute, the eighth only moves data);
-//   * K (swizzled row image, permutation on the source side) and V (row-major, 32-byte chunks XOR-ed with (row >> 1) & 3) of item i + 1
-//     land by LDS-DMA in a second 56 KiB buffer while item i is computed -- no staging registers, no VALU, no LDS transposition;
-//   * products are v_mfma_f32_16x16x32 (r03; the GEMMs' instruction: 11 % less energy per flop than 32x32x16 on this part):
+//   * one persistent workgroup per CU, SIXTEEN waves (four per SIMD), walks (image, head) items; wave w owns the 16 queries 16 w .. 16 w + 15
+//     of the item (197 tokens: 13 waves compute, three only move data).  A wave issues its softmax arithmetic in order, about one
+//     instruction per 6 cycles (tools/issue_probe.hip: 32 v_fmamk 196 cycles, 16 v_exp_f32 168, for one wave and for two), and a SIMD
+//     arbitrates by age: with eight waves of 32 queries the second wave of a SIMD took 5500 cycles for the softmax the first one did in
+//     3300 (clock stamps, profiles/r03/attention_stamps.txt);
+//   * K (swizzled row image, permutation on the source side) and V (row-major, 32-byte chunks XOR-ed with (row >> 1) & 3) land by LDS-DMA
+//     -- no staging registers, no VALU, no LDS transposition -- in a ring of item buffers: THREE for 193..208 tokens (208-row images,
+//     3 x 52 KiB = 156 of the 160 KiB), so item i + 2 is requested while item i is computed and the memory system always holds one whole
+//     item per CU beyond the one being waited for (with two buffers the launch ran 36 us where its memory traffic alone takes 25 and its
+//     arithmetic alone 27); two buffers of 224 rows above 208 tokens;
+//   * products are v_mfma_f32_16x16x32 (the GEMMs' instruction: 11 % less energy per flop than 32x32x16 on this part):
 //     S^T = K . Q^T as 16-key x 16-query tiles, so a query's scores sit in the 4 lanes (lane & 15, lane >> 4 = 0..3) and the softmax
 //     reductions are in-register plus two cross-row shuffles; the probabilities go from the accumulator registers straight into the
 //     B operand of O^T = V^T . P^T (k-slot j of lane group g = key 4 g + j of the first, 16 + 4 g + (j - 4) of the second 16-key tile
-//     of a 32-key step), and the V^T fragments in that same key order come out of two ds_read_b64_tr_b16 each;
-//   * key tiles and query tiles that hold no real token are skipped (197 tokens: 13 of 14 key tiles, 13 of 14 query tiles);
-//   * the DMA of the next item is issued AFTER the QK^T products (hipcc waits vmcnt(0) before the first use of the Q registers,
-//     which were loaded one item earlier: nothing else may be in flight then), so it has the softmax and the PV products to land;
-//     one barrier per item.
+//     of a 32-key step), and the V^T fragments in that same key order come out of two ds_read_b64_tr_b16 each; an odd last key tile is
+//     one v_mfma_f32_16x16x16 (same operand layout, half the k-slots);
+//   * key tiles and query tiles that hold no real token do not exist (NT16V: compile-time), so an item's work is ONE basic block;
+//     every LDS read is inline asm with counted lgkmcnt, K fragments two tiles and V^T fragments one key step ahead of their products
+//     (behind the builtins hipcc drains the DMA queue, vmcnt(0), in front of each read -- any of them might alias a landing piece);
+//   * the output leaves as 16-byte stores of whole 64-byte lines: v_permlane16_swap trades the odd head-dim tile of the even lane
+//     row for the even tile of the odd row, so a lane holds 8 consecutive dims of its query (half the store instructions);
+//   * one barrier per item; vector-memory operations retire in issue order, so the wait in front of it counts what was issued AFTER
+//     the loads it needs: the DMA pieces of item i + 2 and this item's stores stay in flight.
 // exp follows AttnExp<T> (device_common.h): F16 = ggml_soft_max's table semantics, BF16 = one f32 exp2 per key.
-// Keys 197..223 read the next image's rows (finite; masked to -inf) or the zeros a buffer load returns out of range.
+// Keys N .. 16 NT16V - 1 read the next image's rows (finite; masked to -inf) or the zeros a buffer load returns out of range.
 // ------------------------------------------------------------------------------------------------
-// QT = 16-query tiles this wave computes (0: the eighth wave, which only moves data; 1: the wave whose second tile holds no real query;
-// 2), NT16V = 16-key tiles that hold a real key (13 for 193..208 tokens, 14 above): both compile-time, so an item's work is ONE basic
-// block -- with run-time tile tests (r03 first build) every tile was its own block and paid its LDS latency alone: read, wait, 4 MFMAs.
-// FLAGS: 0 in the product; ablation builds under -DVITX_LAB only (tools/attn_bench.py, garbage results by design): 1 = no softmax
-// arithmetic, 2 = no K / V DMA after the first item, 4 = no output stores, 8 = no QK^T products, 16 = no PV products, 32 = no Q loads.
-template <typename T, int NKT, int NT16V, int QT, int FLAGS>
+// QT = 1 for a wave that computes, 0 for one that only moves data; NT16V = 16-key tiles that hold a real key (13 for 193..208 tokens,
+// 14 above).  FLAGS: 0 in the product; ablation builds under -DVITX_LAB only (tools/attn_bench.py, garbage results by design): 1 = no
+// softmax arithmetic, 2 = no K / V DMA after the first items, 4 = no output stores, 8 = no QK^T products, 16 = no PV products, 32 = no Q
+// loads, 64 = shader-clock stamps per phase behind the output rows.
+template <typename T, int NT16V, int QT, int FLAGS>
 __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv, T *__restrict__ out, char *smem, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
-    constexpr int NK = NKT * 32, KB = NK * 128, BUF = 2 * KB;       // one item: K image + V image
-    constexpr int PIECES = NK * 8, OPS = (PIECES + 511) / 512;      // 16-byte pieces per image, DMA instructions per thread and image
-    constexpr int NQ = QT > 0 ? QT : 1;
+    constexpr int NROW = NT16V * 16, KB = NROW * 128, BUF = 2 * KB;    // one item: K image + V image
+    constexpr int NBUF = NT16V <= 13 ? 3 : 2, AHEAD = NBUF - 1;         // ring of item buffers, items requested ahead
+    constexpr int NTHR = 1024, PIECES = NROW * 8, OPS = (PIECES + NTHR - 1) / NTHR;   // 16-byte pieces per image, DMA instructions per thread and image
+    constexpr int NKT = (NT16V + 1) / 2;                                // 32-key steps of the PV product (the last one may be half)
+    static_assert(OPS == 2 && NKT == 7, "193..224 tokens");
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef typename Elem<T>::v8 v8;
     typedef typename Pair<T>::v2 v2;
     typedef short s4 __attribute__((ext_vector_type(4)));
     typedef short s8 __attribute__((ext_vector_type(8)));
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     const int row_bytes = 3 * D * 2;
+    const bool second = NTHR + wave * 64 < PIECES;      // wave-uniform: this wave also issues the second (partial) DMA instruction of an image
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)qkv, 0, (int)total_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)out_bytes, 0x00020000);
-    static_assert(OPS <= 4, "at most 256 keys");
     auto item_base = [&](int item) { const int b = item / H, h = item - b * H; return (int)(((size_t)b * N * 3 * D + h * 64) * 2); };     // bytes (< 4 GiB: launcher)
-    // DMA piece it * 512 + tid of an image is image row (64 it + row of piece tid), same 16-byte slot: ONE per-lane offset per image and an
-    // SGPR stride (the kernel sits at the 256-register limit: eight per-piece offsets were spilled, and every reload is a vector-memory
-    // op that drains the DMA queue before the next piece)
+    // DMA piece it * 1024 + tid of an image is image row (128 it + row of piece tid), same 16-byte slot: ONE per-lane offset per image
+    // and an SGPR stride
     int koff0, voff0;
     {
-        int rr, sl; swz_inv(tid, rr, sl);
-        koff0 = rr * row_bytes + D * 2 + sl * 16;
-        const int vr = tid >> 3, vs = (tid & 7) ^ (((vr >> 1) & 3) << 1);          // V image: 32-byte chunk ^ ((row >> 1) & 3); rows 64 it + vr share it
+        int rr, sl; swz_inv(tid & 511, rr, sl);                                    // 512 pieces = one 64-row block of the swizzled image
+        koff0 = ((tid >> 9) * 64 + rr) * row_bytes + D * 2 + sl * 16;
+        const int vr = tid >> 3, vs = (tid & 7) ^ (((vr >> 1) & 3) << 1);          // V image: 32-byte chunk ^ ((row >> 1) & 3); rows 128 it + vr share it
         voff0 = vr * row_bytes + 2 * D * 2 + vs * 16;
     }
     auto stage = [&](int item, char *buf) {
         const int so = __builtin_amdgcn_readfirstlane(item_base(item));
-#pragma unroll
-        for (int it = 0; it < OPS; ++it) {
-            if (it * 512 + wave * 64 < PIECES) {            // wave-uniform: the last instruction covers only part of the image
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + it * 8192 + wave * 1024), 16, koff0, so + it * 64 * row_bytes, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + it * 8192 + wave * 1024), 16, voff0, so + it * 64 * row_bytes, 0, 0);
-            }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + wave * 1024), 16, koff0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + wave * 1024), 16, voff0, so, 0, 0);
+        if (second) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + NTHR * 16 + wave * 1024), 16, koff0, so + (NTHR / 8) * row_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + NTHR * 16 + wave * 1024), 16, voff0, so + (NTHR / 8) * row_bytes, 0, 0);
         }
     };
     // Q fragments (B operand of S^T = K . Q^T): lane (l15 = query of the tile, g4) holds dims k2 * 32 + g4 * 8 .. + 7
-    v8 qf[NQ][2];
+    v8 qf[2];
     auto load_q = [&](int item) {
         const T *base = qkv + (size_t)item_base(item) / 2;
+        const int qrow = min(wave * 16 + l15, N - 1);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            const int qrow = min(wave * 32 + qt * 16 + l15, N - 1);
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) qf[qt][k2] = *(const v8 *)(base + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8);
-        }
+        for (int k2 = 0; k2 < 2; ++k2) qf[k2] = *(const v8 *)(base + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8);
     };
     // fragment addresses: K tile t (16 keys) = parity (t & 1) base + (t >> 1) * 4096; V step ks (32 keys) adds ks * 4096, its second half 2048
     int krd[2][2], vrd[4];
@@ -865,28 +873,29 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
         for (int dt = 0; dt < 4; ++dt) vrd[dt] = KB + r * 128 + ((dt ^ x) << 5) + (l15 & 3) * 8;
     }
     const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char *)smem);
+    // output: after the row swap a lane holds dims 8 (g4 >> 1) .. + 7 of head-dim tile 2 pr + (g4 & 1), pr = 0, 1
+    const int st_lane = (g4 & 1) * 32 + (g4 >> 1) * 16;
 
     int item = blockIdx.x;
     int cur_off = 0;
     stage(item, smem);
+    if (AHEAD == 2 && item + (int)gridDim.x < items) stage(item + gridDim.x, smem + BUF);
     if constexpr (QT > 0) load_q(item);
     __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
     __builtin_amdgcn_s_barrier();
 
     for (; item < items; item += gridDim.x) {
         const int b = item / H, h = item - b * H;
-        const int nitem = item + gridDim.x;
-        f32x4 s[14][NQ];
-        static_assert(NKT == 7 && (NT16V == 13 || NT16V == 14), "literal array bounds");
+        const int nitem = item + gridDim.x, aitem = item + AHEAD * gridDim.x;      // the next item; the item requested during this one
+        const bool ahead = aitem < items && !(FLAGS & 2);
+        const int aoff = cur_off + AHEAD * BUF >= NBUF * BUF ? cur_off + AHEAD * BUF - NBUF * BUF : cur_off + AHEAD * BUF;
+        f32x4 s[14];
         unsigned long long stamp[6];
 #define VITX_STAMP(I) if (FLAGS & 64) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[I]) :: "memory");
         VITX_STAMP(0)
         if constexpr (QT > 0) {
-            // S^T tiles: rows = keys, cols = queries; a tile of padded keys only (t >= NT16V) is never multiplied.  The K fragments of
-            // tile t + KD are requested before the products of tile t (inline asm + counted lgkmcnt, as for V below: left to itself hipcc
-            // requests a tile right before its products, and all seven waves then sit in that LDS latency together after the barrier)
-            constexpr int KD = 4, KS = KD + 1;
-            typedef int i4 __attribute__((ext_vector_type(4)));
+            // S^T tiles: rows = keys, cols = queries.  The K fragments of tile t + KD are requested before the products of tile t
+            constexpr int KD = 2, KS = KD + 1;
             i4 kf[KS][2];
             unsigned ka[2][2];
 #pragma unroll
@@ -910,91 +919,79 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
                 const int behind = 2 * ((t + KD < NT16V ? t + KD : NT16V - 1) - t);        // reads requested after tile t's
                 switch (behind) {
 #define VITX_WK(C) case C: asm volatile("s_waitcnt lgkmcnt(" #C ")" : "+v"(kf[sl][0]), "+v"(kf[sl][1])); break;
-                VITX_WK(0) VITX_WK(2) VITX_WK(4) VITX_WK(6) VITX_WK(8)
+                VITX_WK(0) VITX_WK(2) VITX_WK(4)
 #undef VITX_WK
                 }
                 const v8 k0 = __builtin_bit_cast(v8, kf[sl][0]), k1 = __builtin_bit_cast(v8, kf[sl][1]);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (FLAGS & 8) { s[t][qt] = f32x4{k0[0], k1[1], k0[2], k1[3]}; continue; }
-                    acc = Elem<T>::mfma16(k0, qf[qt][0], acc);
-                    s[t][qt] = Elem<T>::mfma16(k1, qf[qt][1], acc);
-                }
+                if (FLAGS & 8) { s[t] = f32x4{k0[0], k1[1], k0[2], k1[3]}; continue; }
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                acc = Elem<T>::mfma16(k0, qf[0], acc);
+                s[t] = Elem<T>::mfma16(k1, qf[1], acc);
             }
         }
         VITX_STAMP(1)
         __builtin_amdgcn_sched_barrier(0);
-        // (issued at the top of the item instead -- the buffer is free since the barrier -- the DMA costs 1.8 us per 128-image launch:
-        // it then lands while all seven waves read K fragments)
-        if (nitem < items && !(FLAGS & 2)) stage(nitem, smem + (cur_off ^ BUF));      // lands during the softmax and the PV products
+        // Loads for later items, oldest need first (they retire in this order): the next item's Q fragments (this item's are dead), then
+        // the K / V pieces of the item AHEAD, into the buffer the whole workgroup left at the last barrier.  Issued here and not at the
+        // top of the item: beside the K-fragment reads of every wave the DMA cost 1.8 us per 128-image launch.
+        if constexpr (QT > 0) if (nitem < items && !(FLAGS & 32)) load_q(nitem);
+        if (ahead) stage(aitem, smem + aoff);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (QT > 0) {
-            v8 p[7][NQ];
-            float inv[NQ];
+            v8 p[7];
+            float inv;
+            if (FLAGS & 1) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                if (FLAGS & 1) {
-#pragma unroll
-                    for (int ks = 0; ks < NKT; ++ks) {
-                        const f32x4 a = s[2 * ks][qt], c = s[2 * ks + 1 < NT16V ? 2 * ks + 1 : 0][qt];
-                        const v2 e0 = round_pair<T>(a[0], a[1]), e1 = round_pair<T>(a[2], a[3]), e2 = round_pair<T>(c[0], c[1]), e3 = round_pair<T>(c[2], c[3]);
-                        p[ks][qt] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
-                    }
-                    inv[qt] = 1.0f;
-                    continue;
+                for (int ks = 0; ks < NKT; ++ks) {
+                    const f32x4 a = s[2 * ks], c = s[2 * ks + 1 < NT16V ? 2 * ks + 1 : 0];
+                    const v2 e0 = round_pair<T>(a[0], a[1]), e1 = round_pair<T>(a[2], a[3]), e2 = round_pair<T>(c[0], c[1]), e3 = round_pair<T>(c[2], c[3]);
+                    p[ks] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
                 }
-                float mxs = -INFINITY;
+                inv = 1.0f;
+            } else {
+                // row maximum: four independent chains (a single one is 26 dependent v_max3), rows combined in the VALU
+                float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-                for (int t = 0; t < NT16V; ++t)
+                for (int t = 0; t < NT16V; ++t) {
+                    if (t >= 12) {       // only the last two 16-key tiles can hold padded keys (N > 192)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (t >= 12) {       // only the last two 16-key tiles can hold padded keys (N > 192)
-                            const int key = t * 16 + 4 * g4 + r;
-                            if (key >= N) s[t][qt][r] = -INFINITY;
-                        }
-                        mxs = fmaxf(mxs, s[t][qt][r]);
+                        for (int r = 0; r < 4; ++r) if (t * 16 + 4 * g4 + r >= N) s[t][r] = -INFINITY;
                     }
-                mxs = fmaxf(mxs, __shfl_xor(mxs, 16));
-                mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+                    mx4[t & 3] = fmaxf(fmaxf(mx4[t & 3], s[t][0]), s[t][1]);       // v_max3_f32
+                    mx4[t & 3] = fmaxf(fmaxf(mx4[t & 3], s[t][2]), s[t][3]);
+                }
+                const float mxs = rows4_max(fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3])));
                 const float nmx = -AttnExp<T>::kScale * mxs;
-                float sum = 0.0f;
+                float sum2[2] = {0.0f, 0.0f};
 #pragma unroll
                 for (int ks = 0; ks < NKT; ++ks) {      // numerators per AttnExp<T>; row sum of the ROUNDED values (they are what the PV product sees)
-                    const v2 e0 = AttnExp<T>::pair(s[2 * ks][qt][0], s[2 * ks][qt][1], nmx), e1 = AttnExp<T>::pair(s[2 * ks][qt][2], s[2 * ks][qt][3], nmx);
-                    sum = Pair<T>::sum2(e0, sum); sum = Pair<T>::sum2(e1, sum);
-                    v2 e2 = __builtin_bit_cast(v2, 0u), e3 = __builtin_bit_cast(v2, 0u);       // a tile of padded keys: probability 0
+                    const v2 e0 = AttnExp<T>::pair(s[2 * ks][0], s[2 * ks][1], nmx), e1 = AttnExp<T>::pair(s[2 * ks][2], s[2 * ks][3], nmx);
+                    sum2[0] = Pair<T>::sum2(e0, sum2[0]); sum2[0] = Pair<T>::sum2(e1, sum2[0]);
+                    v2 e2 = __builtin_bit_cast(v2, 0u), e3 = __builtin_bit_cast(v2, 0u);       // (an odd last tile: these slots are not multiplied)
                     if (2 * ks + 1 < NT16V) {
-                        e2 = AttnExp<T>::pair(s[2 * ks + 1][qt][0], s[2 * ks + 1][qt][1], nmx); e3 = AttnExp<T>::pair(s[2 * ks + 1][qt][2], s[2 * ks + 1][qt][3], nmx);
-                        sum = Pair<T>::sum2(e2, sum); sum = Pair<T>::sum2(e3, sum);
+                        e2 = AttnExp<T>::pair(s[2 * ks + 1][0], s[2 * ks + 1][1], nmx); e3 = AttnExp<T>::pair(s[2 * ks + 1][2], s[2 * ks + 1][3], nmx);
+                        sum2[1] = Pair<T>::sum2(e2, sum2[1]); sum2[1] = Pair<T>::sum2(e3, sum2[1]);
                     }
-                    p[ks][qt] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
+                    p[ks] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
                 }
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                inv[qt] = 1.0f / sum;
+                const float sum = rows4_sum(sum2[0] + sum2[1]);
+                inv = 1.0f / sum;
             }
             VITX_STAMP(2)
-            // the next item's Q fragments: issued here (after the scores died: 16 registers the softmax needs) and in flight under the PV products
-            __builtin_amdgcn_sched_barrier(0);
-            if (nitem < items && !(FLAGS & 32)) load_q(nitem);
-            __builtin_amdgcn_sched_barrier(0);
-            // O^T = V^T . P^T: rows = head dims (4 tiles of 16), cols = queries; V^T fragments by transposed LDS reads (inline asm: behind the
-            // builtin hipcc waits vmcnt(0) in front of every transposed read while the next item's LDS-DMA is in flight), the reads of key step
-            // ks + 1 issued ahead of the products of step ks (LDS operations return in order: lgkmcnt(8) = the older eight have landed)
-            f32x4 o[4][NQ];
+            // O^T = V^T . P^T: rows = head dims (4 tiles of 16), cols = queries; V^T fragments by transposed LDS reads, the reads of key
+            // step ks + 1 issued ahead of the products of step ks (LDS operations return in order: lgkmcnt(n) = all but the youngest n landed)
+            f32x4 o[4];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) o[dt][qt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             s4 f[2][4][2];
+            constexpr bool HALF = (NT16V & 1) != 0;         // the last key step holds one 16-key tile
             auto read_v = [&](int ks) {
                 const unsigned cb = lds0 + (unsigned)cur_off + ks * 4096;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const unsigned va = cb + vrd[dt];
                     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[ks & 1][dt][0]) : "v"(va));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[ks & 1][dt][1]) : "v"(va));
+                    if (!(HALF && ks == NKT - 1)) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[ks & 1][dt][1]) : "v"(va));
                 }
             };
             read_v(0);
@@ -1003,84 +1000,102 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
                 const int c = ks & 1;
                 if (ks + 1 < NKT) {
                     read_v(ks + 1);
-                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
-                                                          "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
+                    if (HALF && ks + 1 == NKT - 1)
+                        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
+                                                              "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
+                                                              "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
+                } else if (HALF) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[c][0][0]), "+v"(f[c][1][0]), "+v"(f[c][2][0]), "+v"(f[c][3][0]));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
                                                           "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    const s8 both = __builtin_shufflevector(f[c][dt][0], f[c][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) {
-                        if (FLAGS & 16) { o[dt][qt][0] += (float)both[0] + (float)p[ks][qt][dt]; continue; }
-                        o[dt][qt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p[ks][qt], o[dt][qt]);
+                    if (HALF && ks == NKT - 1) {
+                        const s8 pk = __builtin_bit_cast(s8, p[ks]);
+                        if (FLAGS & 16) { o[dt][0] += (float)f[c][dt][0][0] + (float)pk[dt]; continue; }
+                        o[dt] = Elem<T>::mfma16k16(f[c][dt][0], s4{pk[0], pk[1], pk[2], pk[3]}, o[dt]);
+                        continue;
                     }
+                    const s8 both = __builtin_shufflevector(f[c][dt][0], f[c][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (FLAGS & 16) { o[dt][0] += (float)both[0] + (float)p[ks][dt]; continue; }
+                    o[dt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p[ks], o[dt]);
                 }
             }
             VITX_STAMP(3)
-            // lane (l15 = query, g4) holds O[query][dt * 16 + 4 g4 .. + 3]: 8 bytes per (dt, qt); rows past N go out of the buffer's range and
-            // are dropped, so a wave issues exactly 4 QT stores per item (the counted wait below relies on it)
+            // lane (l15 = query, g4) holds O[query][dt * 16 + 4 g4 .. + 3].  v_permlane16_swap: the even lane row gives its odd tile and
+            // takes the odd row's even tile -> 8 consecutive dims per lane, two 16-byte stores per wave, each covering whole 64-byte
+            // lines; rows past N go out of the buffer's range and are dropped, so a wave issues exactly 2 stores per item (the counted
+            // wait below relies on it)
+            const int qrow = wave * 16 + l15;
+            const unsigned off = qrow < N ? (unsigned)((((size_t)b * N + qrow) * D + h * 64) * 2 + st_lane) : 0xffffff00u;
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const int qrow = wave * 32 + qt * 16 + l15;
-                const unsigned off = qrow < N ? (unsigned)((((size_t)b * N + qrow) * D + h * 64 + g4 * 4) * 2) : 0xfffffff0u;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const v2 lo = round_pair<T>(o[dt][qt][0] * inv[qt], o[dt][qt][1] * inv[qt]), hi = round_pair<T>(o[dt][qt][2] * inv[qt], o[dt][qt][3] * inv[qt]);
-                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                    if (FLAGS & 4) { if (lo[0] == (T)123.0f && hi[1] == (T)77.0f) out[off] = lo[1]; continue; }       // keeps the values alive, never true
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)}, rsrc_o, (int)(off + (qrow < N ? dt * 32 : 0)), 0, 0);
-                }
+            for (int pr = 0; pr < 2; ++pr) {
+                const f32x4 oe = o[2 * pr], oo = o[2 * pr + 1];
+                const v2 elo = round_pair<T>(oe[0] * inv, oe[1] * inv), ehi = round_pair<T>(oe[2] * inv, oe[3] * inv);
+                const v2 olo = round_pair<T>(oo[0] * inv, oo[1] * inv), ohi = round_pair<T>(oo[2] * inv, oo[3] * inv);
+                const auto lo = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, elo), __builtin_bit_cast(unsigned, olo), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ehi), __builtin_bit_cast(unsigned, ohi), false, false);
+                if (FLAGS & 4) { if (lo[0] == 0x12345678u && hi[1] == 0x9abcdef0u) out[off] = (T)1.0f; continue; }       // keeps the values alive, never true
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lo[0], hi[0], lo[1], hi[1]}, rsrc_o, (int)(off + pr * 64), 0, 0);
             }
         }
-        // The next item's K / V and Q must have landed; this wave's output stores are YOUNGER than those loads and may stay in flight
-        // (vector-memory operations retire in issue order on gfx9: the counted wait skips exactly the stores, as gemm_pp.hip does).
         VITX_STAMP(4)
-        if constexpr (QT == 2 && !(FLAGS & 4)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (QT == 1 && !(FLAGS & 4)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The next item's K / V (requested AHEAD items ago, or just now with two buffers) and Q must have landed.  Younger than those loads
+        // and allowed to stay in flight: with three buffers the pieces of item i + 2 (2 or 4 per wave), and this wave's 2 output stores.
+        {
+            constexpr int ST = (QT > 0 && !(FLAGS & 4)) ? 2 : 0;
+            if (AHEAD == 2 && ahead) {
+                if (second) { if constexpr (ST) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else { if constexpr (ST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+            } else {
+                if constexpr (ST) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
         VITX_STAMP(5)
         if ((FLAGS & 64) && blockIdx.x == 0 && lane == 0 && item / (int)gridDim.x < 6) {       // lab: [wave][item][6] shader-clock stamps behind the output rows
             unsigned long long *dbg = (unsigned long long *)((char *)out + out_bytes) + (wave * 6 + item / gridDim.x) * 6;
-            for (int i = 0; i < 6; ++i) dbg[i] = (QT == 0 && i >= 1 && i <= 3) ? stamp[0] : stamp[i];
+            for (int i = 0; i < 6; ++i) dbg[i] = (QT == 0 && i >= 2 && i <= 3) ? stamp[1] : stamp[i];
         }
 #undef VITX_STAMP
         __builtin_amdgcn_s_barrier();             // every wave is done with this item's buffer; the next one is visible to all
-        if (!(FLAGS & 2)) cur_off ^= BUF;
+        if (!(FLAGS & 2)) cur_off = cur_off + BUF >= NBUF * BUF ? 0 : cur_off + BUF;
     }
 }
 
-template <typename T, int NKT, int NT16V, int FLAGS = 0>
-__global__ __launch_bounds__(512, 2) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
+template <typename T, int NT16V, int FLAGS = 0>
+__global__ __launch_bounds__(1024) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= items) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // every wave runs the same number of items and barriers, whichever build of the loop it takes
-    if (wave >= NKT) attention_persist_loop<T, NKT, NT16V, 0, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
-    else if (wave * 32 + 16 < NT16V * 16) attention_persist_loop<T, NKT, NT16V, 2, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
-    else attention_persist_loop<T, NKT, NT16V, 1, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
+    if (wave < NT16V) attention_persist_loop<T, NT16V, 1, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
+    else attention_persist_loop<T, NT16V, 0, FLAGS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes);
 }
+template <int NT16V> constexpr int attention_persist_lds() { return (NT16V <= 13 ? 3 : 2) * 2 * NT16V * 16 * 128; }      // 156 KiB / 112 KiB
 template <typename T>
 static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img, int N, int D, int H, int n_cu, hipStream_t stream, int flags = 0) {
-    constexpr int NKT = 7, lds = 2 * 2 * NKT * 32 * 128;          // two items x (K + V) x 224 rows x 128 B = 112 KiB
     if (n_img == 0) {       // device bring-up
-        hipError_t e = hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        return e != hipSuccess ? e : hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void *)attention_persist_kernel<T, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, attention_persist_lds<13>());
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void *)attention_persist_kernel<T, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, attention_persist_lds<14>());
     }
     const size_t total = (size_t)n_img * N * 3 * D * 2;
     if (total >= 0xf0000000u) return hipErrorInvalidValue;          // 32-bit buffer offsets
     const int items = n_img * H;
     const int grid = items < n_cu ? items : n_cu;
 #ifdef VITX_LAB
-#define VITX_PERSIST_LAB(F) case F: { static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void *)attention_persist_kernel<T, NKT, 13, F>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
-        hipLaunchKernelGGL((attention_persist_kernel<T, NKT, 13, F>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3)); return hipGetLastError(); }
-    if (flags && N <= 208) switch (flags) { VITX_PERSIST_LAB(1) VITX_PERSIST_LAB(2) VITX_PERSIST_LAB(4) VITX_PERSIST_LAB(8) VITX_PERSIST_LAB(16) VITX_PERSIST_LAB(32) VITX_PERSIST_LAB(25) VITX_PERSIST_LAB(38) VITX_PERSIST_LAB(63) VITX_PERSIST_LAB(64) default: return hipErrorInvalidValue; }
+#define VITX_PERSIST_LAB(F) case F: { static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void *)attention_persist_kernel<T, 13, F>, hipFuncAttributeMaxDynamicSharedMemorySize, attention_persist_lds<13>()); } \
+        hipLaunchKernelGGL((attention_persist_kernel<T, 13, F>), dim3(grid), dim3(1024), attention_persist_lds<13>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3)); return hipGetLastError(); }
+    if (flags && N <= 208) switch (flags) {
+        VITX_PERSIST_LAB(1) VITX_PERSIST_LAB(2) VITX_PERSIST_LAB(4) VITX_PERSIST_LAB(8) VITX_PERSIST_LAB(16) VITX_PERSIST_LAB(32) VITX_PERSIST_LAB(25) VITX_PERSIST_LAB(38) VITX_PERSIST_LAB(64)
+        default: return hipErrorInvalidValue; }
 #undef VITX_PERSIST_LAB
 #endif
-    if (N <= 208) hipLaunchKernelGGL((attention_persist_kernel<T, NKT, 13>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
-    else hipLaunchKernelGGL((attention_persist_kernel<T, NKT, 14>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
+    if (N <= 208) hipLaunchKernelGGL((attention_persist_kernel<T, 13>), dim3(grid), dim3(1024), attention_persist_lds<13>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
+    else hipLaunchKernelGGL((attention_persist_kernel<T, 14>), dim3(grid), dim3(1024), attention_persist_lds<14>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
     return hipGetLastError();
 }
 bool attention_persist_supports(int n_img, int N, int D) { return N > 192 && N <= 224 && (size_t)n_img * N * 3 * D * 2 < 0xf0000000u; }
