@@ -41,7 +41,7 @@ if kern >= 16 and (kern >> 4) & 64:      # lab build: per-phase shader-clock sta
     NW = 16
     st = out_all[n_img * N:].view(torch.int64).flatten()[:NW * 6 * 6].view(NW, 6, 6).cpu()
     t00 = int(st[0, 0, 0])
-    names = ["QK^T", "softmax", "PV", "stores+wait", "barrier"]
+    names = ["QK^T", "softmax", "PV", "stores+wait", "barrier"] if (kern >> 4) < 128 else ["even interval", "wait+barrier", "odd interval", "wait", "-"]
     for w in range(NW):
         for it in range(2, 4):
             d = [int(st[w, it, i + 1] - st[w, it, i]) for i in range(5)]
