@@ -1066,281 +1066,6 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same item walk with the sixteen waves in TWO HALVES HALF AN ITEM APART (193..208 tokens: it needs the ring of three buffers).
-// With one barrier per item every wave of a SIMD multiplies QK^T, then every wave runs its softmax, then every wave multiplies PV: the
-// matrix pipe and the VALU take turns (MFMA busy 18 %, VALU issue 34 % of the cycles, profiles/r03/attention_pmc.txt).  Here an item
-// interval has two barriers and each SIMD holds waves of both halves:
-//     interval 2r     | early half: QK^T(r), softmax(r)        | late half: PV(r - 1), stores(r - 1)
-//     interval 2r + 1 | early half: PV(r), stores(r)           | late half: QK^T(r), softmax(r)          (+ every wave: request item r + 2)
-// so one half's softmax always runs beside the other half's products.  Item r's buffer is read during intervals 2r .. 2r + 2 and
-// receives item r + 3 from interval 2r + 3 on; the late half carries its probabilities across a barrier in registers.
-// GROUP: 0 = early, 1 = late; QT = 1 for a wave that computes (its 16-query tile is `tile`), 0 for one that only moves data.
-// STAMPS (lab only): shader-clock stamps per interval behind the output rows.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int NT16V, int GROUP, int QT, bool STAMPS>
-__device__ __forceinline__ void attention_split_loop(const T *__restrict__ qkv, T *__restrict__ out, char *smem, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes, int tile) {
-    constexpr int NROW = NT16V * 16, KB = NROW * 128, BUF = 2 * KB, NBUF = 3;
-    constexpr int NTHR = 1024, PIECES = NROW * 8;
-    constexpr int NKT = (NT16V + 1) / 2;
-    static_assert(NT16V == 13 && NKT == 7, "193..208 tokens");
-    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    typedef typename Elem<T>::v8 v8;
-    typedef typename Pair<T>::v2 v2;
-    typedef short s4 __attribute__((ext_vector_type(4)));
-    typedef short s8 __attribute__((ext_vector_type(8)));
-    typedef int i4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const int row_bytes = 3 * D * 2;
-    const bool second = NTHR + wave * 64 < PIECES;      // wave-uniform: this wave also issues the second (partial) DMA instruction of an image
-
-    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)qkv, 0, (int)total_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)out_bytes, 0x00020000);
-    auto item_base = [&](int item) { const int b = item / H, h = item - b * H; return (int)(((size_t)b * N * 3 * D + h * 64) * 2); };
-    int koff0, voff0;
-    {
-        int rr, sl; swz_inv(tid & 511, rr, sl);
-        koff0 = ((tid >> 9) * 64 + rr) * row_bytes + D * 2 + sl * 16;
-        const int vr = tid >> 3, vs = (tid & 7) ^ (((vr >> 1) & 3) << 1);
-        voff0 = vr * row_bytes + 2 * D * 2 + vs * 16;
-    }
-    auto stage = [&](int item, char *buf) {
-        const int so = __builtin_amdgcn_readfirstlane(item_base(item));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + wave * 1024), 16, koff0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + wave * 1024), 16, voff0, so, 0, 0);
-        if (second) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + NTHR * 16 + wave * 1024), 16, koff0, so + (NTHR / 8) * row_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + NTHR * 16 + wave * 1024), 16, voff0, so + (NTHR / 8) * row_bytes, 0, 0);
-        }
-    };
-    v8 qf[2];
-    auto load_q = [&](int item) {
-        const T *base = qkv + (size_t)item_base(item) / 2;
-        const int qrow = min(tile * 16 + l15, N - 1);
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) qf[k2] = *(const v8 *)(base + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8);
-    };
-    int krd[2][2], vrd[4];
-#pragma unroll
-    for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) krd[pz][k2] = swz_byte(pz * 16 + l15, k2 * 4 + g4);
-    {
-        const int r = 4 * g4 + (l15 >> 2), x = (r >> 1) & 3;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vrd[dt] = KB + r * 128 + ((dt ^ x) << 5) + (l15 & 3) * 8;
-    }
-    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char *)smem);
-    const int st_lane = (g4 & 1) * 32 + (g4 >> 1) * 16;
-
-    const int first = blockIdx.x, stride = gridDim.x;
-    const int n_items = (items - first + stride - 1) / stride;          // rounds of this workgroup (>= 1: the kernel returns otherwise)
-    v8 p[7];
-    float inv = 0.0f;
-
-    // QK^T, the next item's Q fragments, softmax: fills p / inv from the K image at byte offset boff
-    auto phase1 = [&](int r, int boff) {
-        f32x4 s[14];
-        constexpr int KD = 2, KS = KD + 1;
-        i4 kf[KS][2];
-        unsigned ka[2][2];
-#pragma unroll
-        for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) ka[pz][k2] = lds0 + (unsigned)boff + krd[pz][k2];
-        auto read_k = [&](int t) {
-            const int sl = t % KS;
-            switch (t >> 1) {
-#define VITX_RK(I) case I: asm volatile("ds_read_b128 %0, %1 offset:" #I "*4096" : "=v"(kf[sl][0]) : "v"(ka[t & 1][0])); asm volatile("ds_read_b128 %0, %1 offset:" #I "*4096" : "=v"(kf[sl][1]) : "v"(ka[t & 1][1])); break;
-            VITX_RK(0) VITX_RK(1) VITX_RK(2) VITX_RK(3) VITX_RK(4) VITX_RK(5) VITX_RK(6)
-#undef VITX_RK
-            }
-        };
-#pragma unroll
-        for (int t = 0; t < KD; ++t) read_k(t);
-#pragma unroll
-        for (int t = 0; t < NT16V; ++t) {
-            const int sl = t % KS;
-            if (t + KD < NT16V) read_k(t + KD);
-            const int behind = 2 * ((t + KD < NT16V ? t + KD : NT16V - 1) - t);
-            switch (behind) {
-#define VITX_WK(C) case C: asm volatile("s_waitcnt lgkmcnt(" #C ")" : "+v"(kf[sl][0]), "+v"(kf[sl][1])); break;
-            VITX_WK(0) VITX_WK(2) VITX_WK(4)
-#undef VITX_WK
-            }
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            acc = Elem<T>::mfma16(__builtin_bit_cast(v8, kf[sl][0]), qf[0], acc);
-            s[t] = Elem<T>::mfma16(__builtin_bit_cast(v8, kf[sl][1]), qf[1], acc);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (r + 1 < n_items) load_q(first + (r + 1) * stride);         // this item's Q fragments are dead
-        __builtin_amdgcn_sched_barrier(0);
-        float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int t = 0; t < NT16V; ++t) {
-            if (t >= 12) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (t * 16 + 4 * g4 + q >= N) s[t][q] = -INFINITY;
-            }
-            mx4[t & 3] = fmaxf(fmaxf(mx4[t & 3], s[t][0]), s[t][1]);
-            mx4[t & 3] = fmaxf(fmaxf(mx4[t & 3], s[t][2]), s[t][3]);
-        }
-        const float mxs = rows4_max(fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3])));
-        const float nmx = -AttnExp<T>::kScale * mxs;
-        float sum2[2] = {0.0f, 0.0f};
-#pragma unroll
-        for (int ks = 0; ks < NKT; ++ks) {
-            const v2 e0 = AttnExp<T>::pair(s[2 * ks][0], s[2 * ks][1], nmx), e1 = AttnExp<T>::pair(s[2 * ks][2], s[2 * ks][3], nmx);
-            sum2[0] = Pair<T>::sum2(e0, sum2[0]); sum2[0] = Pair<T>::sum2(e1, sum2[0]);
-            v2 e2 = __builtin_bit_cast(v2, 0u), e3 = __builtin_bit_cast(v2, 0u);
-            if (2 * ks + 1 < NT16V) {
-                e2 = AttnExp<T>::pair(s[2 * ks + 1][0], s[2 * ks + 1][1], nmx); e3 = AttnExp<T>::pair(s[2 * ks + 1][2], s[2 * ks + 1][3], nmx);
-                sum2[1] = Pair<T>::sum2(e2, sum2[1]); sum2[1] = Pair<T>::sum2(e3, sum2[1]);
-            }
-            p[ks] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
-        }
-        inv = 1.0f / rows4_sum(sum2[0] + sum2[1]);
-    };
-    // PV from the V image at byte offset boff, output rows of item r
-    auto phase2 = [&](int r, int boff) {
-        const int item = first + r * stride;
-        const int b = item / H, h = item - b * H;
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        s4 f[2][4][2];
-        auto read_v = [&](int ks) {
-            const unsigned cb = lds0 + (unsigned)boff + ks * 4096;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const unsigned va = cb + vrd[dt];
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[ks & 1][dt][0]) : "v"(va));
-                if (ks != NKT - 1) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(f[ks & 1][dt][1]) : "v"(va));
-            }
-        };
-        read_v(0);
-#pragma unroll
-        for (int ks = 0; ks < NKT; ++ks) {
-            const int c = ks & 1;
-            if (ks + 1 < NKT) {
-                read_v(ks + 1);
-                if (ks + 1 == NKT - 1)
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
-                                                          "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
-                else
-                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
-                                                          "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[c][0][0]), "+v"(f[c][1][0]), "+v"(f[c][2][0]), "+v"(f[c][3][0]));
-            }
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                if (ks == NKT - 1) {
-                    const s8 pk = __builtin_bit_cast(s8, p[ks]);
-                    o[dt] = Elem<T>::mfma16k16(f[c][dt][0], s4{pk[0], pk[1], pk[2], pk[3]}, o[dt]);
-                } else {
-                    const s8 both = __builtin_shufflevector(f[c][dt][0], f[c][dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[dt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p[ks], o[dt]);
-                }
-            }
-        }
-        const int qrow = tile * 16 + l15;
-        const unsigned off = qrow < N ? (unsigned)((((size_t)b * N + qrow) * D + h * 64) * 2 + st_lane) : 0xffffff00u;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const f32x4 oe = o[2 * pr], oo = o[2 * pr + 1];
-            const v2 elo = round_pair<T>(oe[0] * inv, oe[1] * inv), ehi = round_pair<T>(oe[2] * inv, oe[3] * inv);
-            const v2 olo = round_pair<T>(oo[0] * inv, oo[1] * inv), ohi = round_pair<T>(oo[2] * inv, oo[3] * inv);
-            const auto lo = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, elo), __builtin_bit_cast(unsigned, olo), false, false);
-            const auto hi = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ehi), __builtin_bit_cast(unsigned, ohi), false, false);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lo[0], hi[0], lo[1], hi[1]}, rsrc_o, (int)(off + pr * 64), 0, 0);
-        }
-    };
-
-    unsigned long long stamp[5];
-#define VITX_STAMP(I) if (STAMPS) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[I]) :: "memory");
-    stage(first, smem);
-    if (n_items > 1) stage(first + stride, smem + BUF);
-    if constexpr (QT > 0) load_q(first);
-    __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-
-    int cur_off = 0, prev_off = 2 * BUF;       // buffers of items r and r - 1 (= the one item r + 2 goes to)
-    for (int r = 0; r < n_items; ++r) {
-        // ---- interval 2r
-        VITX_STAMP(0)
-        if constexpr (QT > 0) {
-            if (GROUP == 0) phase1(r, cur_off);
-            else if (r > 0) phase2(r - 1, prev_off);
-        }
-        VITX_STAMP(1)
-        // late half: its Q fragments of item r (requested one interval ago) are older than the 2 stores it just issued
-        if (GROUP == 1 && QT > 0 && r > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // ---- interval 2r + 1: item r - 1's buffer is free (the late half left it at the barrier above)
-        VITX_STAMP(2)
-        const bool ahead = r + 2 < n_items;
-        if (ahead) stage(first + (r + 2) * stride, smem + prev_off);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (QT > 0) {
-            if (GROUP == 0) phase2(r, cur_off);
-            else phase1(r, cur_off);
-        }
-        VITX_STAMP(3)
-        // Item r + 1 (requested two intervals ago, or in the prologue) is multiplied by the early half right after this barrier: every
-        // wave's pieces of it must have landed.  Issued after them, and allowed to stay in flight: the pieces of item r + 2 (2 or 4),
-        // plus -- early half -- this item's 2 stores (its Q fragments of item r + 1 are older than both), -- late half -- its 2 loads of
-        // Q(r + 1) (not needed before the barrier after next).
-        {
-            const bool more = r + 1 < n_items;
-            if (QT > 0 && (GROUP == 0 || more)) {
-                if (ahead) { if (second) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                if (ahead) { if (second) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        VITX_STAMP(4)
-        if (STAMPS && blockIdx.x == 0 && lane == 0 && r < 6) {       // lab: [wave][round][6] stamps behind the output rows
-            unsigned long long *dbg = (unsigned long long *)((char *)out + out_bytes) + (wave * 6 + r) * 6;
-            for (int i = 0; i < 5; ++i) dbg[i] = stamp[i];
-            dbg[5] = stamp[4];
-        }
-        __builtin_amdgcn_s_barrier();
-        prev_off = cur_off;
-        cur_off = cur_off + BUF >= NBUF * BUF ? 0 : cur_off + BUF;
-    }
-#undef VITX_STAMP
-    // ---- interval 2 n: the late half's last products
-    if constexpr (QT > 0 && GROUP == 1) phase2(n_items - 1, prev_off);
-}
-
-// Which wave computes which 16-query tile in the split schedule: SIMD s holds waves s, s + 4 (early half) and s + 8, s + 12 (late half);
-// 13 tiles = 4 + 3 + 3 + 3 per SIMD with both halves on every SIMD: early waves 0..6 take tiles 0..6, late waves 8..12 and 15 take 7..12.
-__device__ __forceinline__ int attention_split_tile(int wave) {
-    if (wave < 7) return wave;
-    if (wave >= 8 && wave <= 12) return wave - 1;
-    if (wave == 15) return 12;
-    return -1;
-}
-template <typename T, bool STAMPS = false>
-__global__ __launch_bounds__(1024) void attention_split_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x >= items) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = attention_split_tile(wave);
-    // every wave runs the same number of barriers, whichever build of the loop it takes
-    if (wave < 8) {
-        if (tile >= 0) attention_split_loop<T, 13, 0, 1, STAMPS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes, tile);
-        else attention_split_loop<T, 13, 0, 0, STAMPS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes, 0);
-    } else {
-        if (tile >= 0) attention_split_loop<T, 13, 1, 1, STAMPS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes, tile);
-        else attention_split_loop<T, 13, 1, 0, STAMPS>(qkv, out, smem, N, D, H, items, total_bytes, out_bytes, 0);
-    }
-}
-
 template <typename T, int NT16V, int FLAGS = 0>
 __global__ __launch_bounds__(1024) void attention_persist_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, unsigned total_bytes, unsigned out_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1364,14 +1089,6 @@ static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img
 #ifdef VITX_LAB
 #define VITX_PERSIST_LAB(F) case F: { static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void *)attention_persist_kernel<T, 13, F>, hipFuncAttributeMaxDynamicSharedMemorySize, attention_persist_lds<13>()); } \
         hipLaunchKernelGGL((attention_persist_kernel<T, 13, F>), dim3(grid), dim3(1024), attention_persist_lds<13>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3)); return hipGetLastError(); }
-    if (flags >= 128 && N <= 208) {       // the split schedule (128) and its stamped build (192)
-        static bool once = false;
-        if (!once) { once = true; (void)hipFuncSetAttribute((const void *)attention_split_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, attention_persist_lds<13>());
-                     (void)hipFuncSetAttribute((const void *)attention_split_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, attention_persist_lds<13>()); }
-        if (flags == 192) hipLaunchKernelGGL((attention_split_kernel<T, true>), dim3(grid), dim3(1024), attention_persist_lds<13>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
-        else hipLaunchKernelGGL((attention_split_kernel<T, false>), dim3(grid), dim3(1024), attention_persist_lds<13>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
-        return hipGetLastError();
-    }
     if (flags && N <= 208) switch (flags) {
         VITX_PERSIST_LAB(1) VITX_PERSIST_LAB(2) VITX_PERSIST_LAB(4) VITX_PERSIST_LAB(8) VITX_PERSIST_LAB(16) VITX_PERSIST_LAB(32) VITX_PERSIST_LAB(25) VITX_PERSIST_LAB(38) VITX_PERSIST_LAB(64)
         default: return hipErrorInvalidValue; }
