@@ -91,6 +91,7 @@ struct Tuning {
     int gemm_dbg = 0;        // ablation bits of the ring kernel (honoured under VITX_LAB only)
     int attn_kernel = ATTN_AUTO;
     int attn_flags = 0;      // ablation build of the pipelined attention kernel (exists under VITX_LAB only)
+    int attn_grid = 0;       // persistent attention: workgroups (0 = one per CU)
 };
 // Looks the device up (hipGetDevice when device < 0) and on first use of a device
 // sets the dynamic-LDS attribute of every kernel instantiation on it.  Thread-safe.  Returns nullptr if HIP fails.

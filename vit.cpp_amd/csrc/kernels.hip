@@ -1085,7 +1085,10 @@ static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img
     const size_t total = (size_t)n_img * N * 3 * D * 2;
     if (total >= 0xf0000000u) return hipErrorInvalidValue;          // 32-bit buffer offsets
     const int items = n_img * H;
-    const int grid = items < n_cu ? items : n_cu;
+    // balanced persistent grid (as the GEMMs'): every workgroup walks the same number of items; the CUs a partial last round would have
+    // lit for one item go to the other sub-batch's kernels for the whole launch (1836 items: 230 workgroups x 8 instead of 256 x 7.2)
+    const int rounds = (items + n_cu - 1) / n_cu;
+    const int grid = (items + rounds - 1) / rounds;
 #ifdef VITX_LAB
 #define VITX_PERSIST_LAB(F) case F: { static bool once = false; if (!once) { once = true; (void)hipFuncSetAttribute((const void *)attention_persist_kernel<T, 13, F>, hipFuncAttributeMaxDynamicSharedMemorySize, attention_persist_lds<13>()); } \
         hipLaunchKernelGGL((attention_persist_kernel<T, 13, F>), dim3(grid), dim3(1024), attention_persist_lds<13>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3)); return hipGetLastError(); }
@@ -1117,7 +1120,7 @@ hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *o
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
     // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax)
     if ((t.attn_kernel == ATTN_PERSIST || t.attn_kernel == ATTN_AUTO) && attention_persist_supports(n_img, N, D))
-        return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.n_cu, stream, t.attn_flags) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.n_cu, stream, t.attn_flags);
+        return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags);
     if (t.attn_kernel == ATTN_PERSIST) return hipErrorInvalidValue;
     const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_kernel == ATTN_SINGLE);
     if (t.attn_kernel == ATTN_FLOW || !single)
@@ -1171,6 +1174,7 @@ const Tuning *tuning_for_device(int device) {
     t->pp_flags = env_int("VITX_PP_FLAGS", 0);
     t->gemm_dbg = env_int("VITX_GEMM_DBG", 0);
     t->attn_kernel = env_int("VITX_ATTN_KERNEL", 0);
+    t->attn_grid = env_int("VITX_ATTN_GRID", 0);
 #endif
     const hipError_t e = prepare_device_kernels(*t);
     if (cur != device) (void)hipSetDevice(cur);
