@@ -60,8 +60,9 @@ def convert_hf_model(model, path: str, ftype: int = 1, vitstr: bool = False) -> 
     cfg = model.config
     if vitstr and getattr(cfg, "num_channels", 3) != 1:
         raise ValueError("a ViTSTR model takes one (grey) input channel")
-    if cfg.hidden_size // cfg.num_attention_heads != 64:
-        raise ValueError("the forward path supports head_dim 64 only (every model the reference converts)")
+    hd = cfg.hidden_size // cfg.num_attention_heads
+    if cfg.hidden_size % cfg.num_attention_heads or hd % 8 or not 8 <= hd <= 128:
+        raise ValueError(f"head_dim {hd}: the forward path takes multiples of 8 up to 128 (64 runs the tuned attention kernels)")
     hp = HParams(cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_labels, cfg.patch_size, cfg.image_size, ftype)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     tensors = state_dict_to_timm(sd, cfg.num_hidden_layers)
@@ -105,8 +106,8 @@ def convert_timm_state_dict(sd, path: str, ftype: int = 1, heads: int = 0, id2la
     if Dw != D or P != P2 or g * g + 1 != n_tok or cin not in (1, 3):
         raise ValueError(f"unexpected shapes: patch kernel {t['patch_embed.proj.weight'].shape}, pos_embed {t['pos_embed'].shape}")
     H = heads or D // 64
-    if D % H or D // H != 64:
-        raise ValueError(f"head_dim {D // H if H and D % H == 0 else '?'}: the forward path supports 64 only (pass --heads for a model whose head_dim is not hidden/64)")
+    if D % H or (D // H) % 8 or not 8 <= D // H <= 128:
+        raise ValueError(f"head_dim {D // H if H and D % H == 0 else '?'}: the forward path takes multiples of 8 up to 128 (pass --heads for a model whose head_dim is not 64)")
     hp = HParams(D, L, H, int(t["head.weight"].shape[0]), int(P), g * int(P), ftype)
     if cin == 1 and id2label is None:
         from .synth import VITSTR_LABELS

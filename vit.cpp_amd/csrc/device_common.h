@@ -103,6 +103,26 @@ template <> struct AttnExp<__bf16> {
     }
 };
 
+// The same with a run-time score scale 1 / sqrt(head_dim) (attention_generic_kernel: head dims other than 64; ggml_scale_inplace,
+// /root/reference/vit.cpp:853).  k(scale) is what multiplies the raw score AND the row maximum (nmx = -max * k).
+template <typename T> struct AttnExpRt;
+template <> struct AttnExpRt<_Float16> {
+    static __device__ __forceinline__ float k(float scale) { return scale; }
+    static __device__ __forceinline__ Pair<_Float16>::v2 pair(float s0, float s1, float nmx, float kk) {
+        const f32x2 d = __builtin_elementwise_fma(f32x2{s0, s1}, f32x2{kk, kk}, f32x2{nmx, nmx});
+        const Pair<_Float16>::v2 dh = round_pair<_Float16>(d[0], d[1]);
+        const f32x2 t = f32x2{(float)dh[0], (float)dh[1]} * f32x2{1.44269504f, 1.44269504f};
+        return round_pair<_Float16>(__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]));
+    }
+};
+template <> struct AttnExpRt<__bf16> {
+    static __device__ __forceinline__ float k(float scale) { return scale * 1.44269504088896340736f; }
+    static __device__ __forceinline__ Pair<__bf16>::v2 pair(float s0, float s1, float nmx, float kk) {
+        const f32x2 d = __builtin_elementwise_fma(f32x2{s0, s1}, f32x2{kk, kk}, f32x2{nmx, nmx});
+        return round_pair<__bf16>(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
+    }
+};
+
 // Reductions over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48) without the LDS crossbar: v_permlane16_swap /
 // v_permlane32_swap (gfx950) exchange rows in the VALU -- no ds_bpermute, no lgkmcnt wait in the middle of a dependent chain.
 // swap16(x, x) leaves {row 0, row 0, row 2, row 2} and {row 1, row 1, row 3, row 3}; swap32 of the result {lower half, lower half} and

@@ -295,7 +295,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("vitx_ctx_create: no HIP device available (this engine has no CPU fallback)"); return VITX_ERR_HIP; }
     if (device < 0 || device >= ndev) { set_error("vitx_ctx_create: device %d out of range (%d devices)", device, ndev); return VITX_ERR_ARG; }
     const vitx_hparams &hp = m->hp;
-    if (hp.hidden_size != hp.num_attention_heads * 64) { set_error("vitx_ctx_create: head_dim %d unsupported (kernels are written for 64)", hp.hidden_size / hp.num_attention_heads); return VITX_ERR_UNSUPPORTED; }
+    if (hp.num_attention_heads <= 0 || hp.hidden_size % hp.num_attention_heads) { set_error("vitx_ctx_create: hidden_size %d is not a multiple of %d heads", hp.hidden_size, hp.num_attention_heads); return VITX_ERR_UNSUPPORTED; }
     if (hp.hidden_size % 64) { set_error("vitx_ctx_create: hidden_size must be a multiple of 64"); return VITX_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<vitx_ctx> c(new (std::nothrow) vitx_ctx());
@@ -309,7 +309,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->C_pad = round_up(c->C, c->tn);
     // validate against what the kernels are actually instantiated for (a context that would fail on its first forward is refused here)
     if (!attention_supports(c->N, c->D, c->H)) {
-        set_error("vitx_ctx_create: attention needs head_dim 64 and at least one token (%d tokens, img_size %d, patch_size %d)", c->N, c->S, c->P);
+        set_error("vitx_ctx_create: attention needs a head_dim that is a multiple of 8 up to 128 (this model: %d) and at least one token (%d tokens, img_size %d, patch_size %d)", c->D / c->H, c->N, c->S, c->P);
         return VITX_ERR_UNSUPPORTED;
     }
     if (!layernorm_supports(c->D)) { set_error("vitx_ctx_create: hidden_size %d has no LayerNorm instantiation (64, 128, 192, 256, 384, 512, 768, 1024, 1280, 1536)", c->D); return VITX_ERR_UNSUPPORTED; }

@@ -121,7 +121,7 @@ void patch_embed_permute_k(const uint16_t *w, uint16_t *w_perm, int N, int Cin, 
 hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream, int group = 1, long gstride = 0);
 // fused per-(image,head) attention  (vit.cpp:826-866)
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream);
-bool attention_supports(int N, int D, int H);     // head_dim 64, any token count
+bool attention_supports(int N, int D, int H);     // any token count; head_dim 64 (tuned kernels) or any other multiple of 8 up to 128 (generic kernel)
 bool attention_single_pass_supports(int N);       // instantiation table of the register-resident kernel
 bool layernorm_supports(int D);
 // class softmax with the reference's fp16 (or bf16) exp rounding (vit.cpp:931)

@@ -1101,6 +1101,132 @@ static hipError_t launch_attention_persist(const void *qkv, void *out, int n_img
     else hipLaunchKernelGGL((attention_persist_kernel<T, 14>), dim3(grid), dim3(1024), attention_persist_lds<14>(), stream, (const T *)qkv, (T *)out, N, D, H, items, (unsigned)total, (unsigned)(total / 3));
     return hipGetLastError();
 }
+// ------------------------------------------------------------------------------------------------
+// Attention for head dimensions other than 64 (vit.cpp:826-866 is generic in n_enc_head_dim; timm's ViT-H/14 has 80, 8-head variants
+// 96 / 128, small models 32): any multiple of 8 up to 128.  Not a tuned kernel -- every model the benchmarks name has head_dim 64 -- but
+// the same arithmetic as the other three: S^T = K . Q^T by v_mfma_f32_16x16x32 over the head dim zero-padded to a multiple of 32, two
+// passes over the keys (row maximum; then exp per AttnExpRt<T>, row sum of the rounded numerators, O^T = V^T . P^T), scores in the
+// four lanes (lane & 15, lane >> 4) of a query.  One wave per 16-query tile, four tiles per workgroup, no workgroup barrier: K
+// fragments come straight from global memory (16-byte pieces of a key's head slice; pieces past head_dim are zeros), a 32-key step
+// of V goes through the wave's own 8 KiB of LDS to be read back transposed (ds_read_b64_tr_b16).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NK2>
+__global__ __launch_bounds__(256) void attention_generic_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int DH, float scale, int qblocks) {
+    constexpr int DHP = NK2 * 32, ND = DHP / 16, ROWB = DHP * 2;       // padded head dim, 16-dim output tiles, LDS row bytes
+    __shared__ __attribute__((aligned(16))) char smem[4 * 32 * ROWB];
+    typedef typename Elem<T>::v8 v8;
+    typedef typename Pair<T>::v2 v2;
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x / qblocks, qb = blockIdx.x - item * qblocks;
+    const int b = item / H, h = item - b * H;
+    const int q0 = (qb * 4 + wave) * 16;
+    if (q0 >= N) return;                              // no barrier in this kernel: a wave without queries simply leaves
+    const size_t row_el = (size_t)3 * D;
+    const T *base = qkv + (size_t)b * N * row_el + (size_t)h * DH;        // q of token 0; k at + D, v at + 2 D
+    const v8 zero8 = __builtin_bit_cast(v8, (int __attribute__((ext_vector_type(4)))){0, 0, 0, 0});
+    // Q fragments (B operand): lane (l15 = query, g4) holds dims k2 * 32 + g4 * 8 .. + 7
+    v8 qf[NK2];
+    {
+        const int qrow = min(q0 + l15, N - 1);
+#pragma unroll
+        for (int k2 = 0; k2 < NK2; ++k2) { const int d0 = k2 * 32 + g4 * 8; qf[k2] = d0 < DH ? *(const v8 *)(base + (size_t)qrow * row_el + d0) : zero8; }
+    }
+    auto score_tile = [&](int t) {                   // S^T tile t: rows = keys 16 t .., cols = queries; acc[r] = key 16 t + 4 g4 + r
+        const int krow = min(t * 16 + l15, N - 1);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k2 = 0; k2 < NK2; ++k2) {
+            const int d0 = k2 * 32 + g4 * 8;
+            const v8 kf = d0 < DH ? *(const v8 *)(base + D + (size_t)krow * row_el + d0) : zero8;
+            acc = Elem<T>::mfma16(kf, qf[k2], acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (t * 16 + 4 * g4 + r >= N) acc[r] = -INFINITY;
+        return acc;
+    };
+    // ---- pass 1: row maximum
+    const int nt16 = (N + 15) / 16, nks = (N + 31) / 32;
+    float mx = -INFINITY;
+    for (int t = 0; t < nt16; ++t) {
+        const f32x4 sc = score_tile(t);
+        mx = fmaxf(fmaxf(mx, sc[0]), sc[1]); mx = fmaxf(fmaxf(mx, sc[2]), sc[3]);
+    }
+    mx = rows4_max(mx);
+    const float kk = AttnExpRt<T>::k(scale), nmx = -kk * mx;
+    // ---- pass 2: numerators, row sum, PV
+    f32x4 o[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) o[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float sum = 0.0f;
+    char *my = smem + wave * (32 * ROWB);
+    const unsigned lds_my = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) char *)my);
+    const unsigned tr_off = (4 * g4 + (l15 >> 2)) * ROWB + (l15 & 3) * 8;      // this lane's V row of a 16-key group, 4-dim piece of a 16-dim tile
+    for (int ks = 0; ks < nks; ++ks) {
+        const f32x4 sa = score_tile(2 * ks);
+        f32x4 sb = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (2 * ks + 1 < nt16) sb = score_tile(2 * ks + 1);
+        const v2 e0 = AttnExpRt<T>::pair(sa[0], sa[1], nmx, kk), e1 = AttnExpRt<T>::pair(sa[2], sa[3], nmx, kk);
+        const v2 e2 = AttnExpRt<T>::pair(sb[0], sb[1], nmx, kk), e3 = AttnExpRt<T>::pair(sb[2], sb[3], nmx, kk);
+        sum = Pair<T>::sum2(e0, sum); sum = Pair<T>::sum2(e1, sum); sum = Pair<T>::sum2(e2, sum); sum = Pair<T>::sum2(e3, sum);
+        const v8 pk = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
+        // V rows 32 ks .. + 31 (clamped: their probabilities are zero past N) x DHP dims into the wave's LDS, row-major
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous step's transposed reads are done with it
+#pragma unroll
+        for (int i = 0; i < (32 * DHP / 8 + 63) / 64; ++i) {
+            const int pi = i * 64 + lane, row = pi / (DHP / 8), c8 = pi - row * (DHP / 8);
+            if (pi < 32 * DHP / 8) {
+                const int vrow = min(ks * 32 + row, N - 1);
+                const v8 vv = c8 * 8 < DH ? *(const v8 *)(base + 2 * D + (size_t)vrow * row_el + c8 * 8) : zero8;
+                *(v8 *)(my + row * ROWB + c8 * 16) = vv;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            s4 f0, f1;
+            const unsigned va = lds_my + tr_off + dt * 32;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f0) : "v"(va) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f1) : "v"(va + 16 * ROWB) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0), "+v"(f1));
+            const s8 both = __builtin_shufflevector(f0, f1, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[dt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), pk, o[dt]);
+        }
+    }
+    const float inv = 1.0f / rows4_sum(sum);
+    // lane (l15 = query, g4) holds O[query][dt * 16 + 4 g4 .. + 3]
+    const int qrow = q0 + l15;
+    if (qrow < N) {
+        T *orow = out + ((size_t)b * N + qrow) * D + (size_t)h * DH;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const int d0 = dt * 16 + 4 * g4;
+            if (d0 < DH) {
+                const v2 lo = round_pair<T>(o[dt][0] * inv, o[dt][1] * inv), hi = round_pair<T>(o[dt][2] * inv, o[dt][3] * inv);
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                *(u32x2_t *)(orow + d0) = u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+            }
+        }
+    }
+}
+bool attention_generic_supports(int D, int H) { return H > 0 && D % H == 0 && (D / H) % 8 == 0 && D / H >= 8 && D / H <= 128; }
+template <typename T>
+static hipError_t launch_attention_generic(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
+    const int DH = D / H, nk2 = (DH + 31) / 32, qblocks = (N + 63) / 64;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const dim3 grid((unsigned)((size_t)n_img * H * qblocks)), blk(256);
+    switch (nk2) {
+    case 1: hipLaunchKernelGGL((attention_generic_kernel<T, 1>), grid, blk, 0, stream, (const T *)qkv, (T *)out, N, D, H, DH, scale, qblocks); break;
+    case 2: hipLaunchKernelGGL((attention_generic_kernel<T, 2>), grid, blk, 0, stream, (const T *)qkv, (T *)out, N, D, H, DH, scale, qblocks); break;
+    case 3: hipLaunchKernelGGL((attention_generic_kernel<T, 3>), grid, blk, 0, stream, (const T *)qkv, (T *)out, N, D, H, DH, scale, qblocks); break;
+    case 4: hipLaunchKernelGGL((attention_generic_kernel<T, 4>), grid, blk, 0, stream, (const T *)qkv, (T *)out, N, D, H, DH, scale, qblocks); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 bool attention_persist_supports(int n_img, int N, int D) { return N > 192 && N <= 224 && (size_t)n_img * N * 3 * D * 2 < 0xf0000000u; }
 
 static const int kAttnNkt[] = {1, 2, 3, 4, 5, 6, 7, 9, 19};      // instantiated key-tile counts (tokens = 32 * nkt, rounded up)
@@ -1109,7 +1235,7 @@ bool attention_single_pass_supports(int N) {
     for (int k : kAttnNkt) if (k == nkt) return true;
     return false;
 }
-bool attention_supports(int N, int D, int H) { return D == H * 64 && N > 0; }      // any token count
+bool attention_supports(int N, int D, int H) { return N > 0 && (D == H * 64 || attention_generic_supports(D, H)); }      // any token count; head_dim 64 (tuned kernels) or any multiple of 8 up to 128
 // Kernel choice (measured, 128 x 12 heads bf16: 197 tokens 52 vs 55 us, 257 tokens 77 vs 92 us single-pass vs pipelined;
 // 64 x 16 heads x 577 tokens 282 vs 241 us -- profiles/r02_attention.txt):
 //   193..224 tokens: the persistent single-pass kernel at EVERY batch size (its 16x16x32 products group the f32 sums differently from the
@@ -1118,6 +1244,7 @@ bool attention_supports(int N, int D, int H) { return D == H * 64 && N > 0; }   
 // t.attn_kernel (vitx_op_attention_ex, tests): ATTN_SINGLE / ATTN_FLOW / ATTN_PERSIST force one family.
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
+    if (D != H * 64) return dtype == DT_F16 ? launch_attention_generic<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_generic<__bf16>(qkv, out, n_img, N, D, H, stream);
     // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax)
     if ((t.attn_kernel == ATTN_PERSIST || t.attn_kernel == ATTN_AUTO) && attention_persist_supports(n_img, N, D))
         return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags);

@@ -22,6 +22,9 @@ CONFIGS = {
     "vit_micro_patch16_64": (128, 2, 2, 10, 16, 64),       # test-only toy (N=17)
     "vit_micro_c37_patch16_64": (128, 2, 2, 37, 16, 64),   # test-only toy with an ODD class count (the head GEMM's last column group is ragged)
     "vit_micro_patch8_224": (128, 2, 2, 10, 8, 224),       # test-only toy with the token count of the reference's default hparams (N=785)
+    "vit_micro_hd32_patch16_64": (128, 2, 4, 10, 16, 64),  # test-only toys with head dims other than 64 (the generic attention kernel): 32,
+    "vit_micro_hd96_patch16_96": (192, 2, 2, 10, 16, 96),  #   96 (N = 37),
+    "vit_mini_hd80_patch14_112": (1280, 2, 16, 10, 14, 112),   # 80 with ViT-H/14's widths (patch 14: N = 65)
     "vit_base_patch8_224": (768, 12, 12, 1000, 8, 224),    # the reference's default hparams (vit.h:22-28)
     "vit_tiny_patch16_224": (192, 12, 3, 1000, 16, 224),
     "vit_small_patch16_224": (384, 12, 6, 1000, 16, 224),
