@@ -61,7 +61,26 @@ def test_attention_poisoned_neighbours(binding, torch_gpu):
     assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("name,n", [("vit_micro_hd32_patch16_64", 5), ("vit_micro_hd96_patch16_96", 3), ("vit_mini_hd80_patch14_112", 3)])
+@pytest.mark.parametrize("D", [320, 448, 576, 640, 896, 1152, 1280, 1408, 1536, 1664, 2048])
+def test_layernorm_other_widths(binding, oracle, torch_gpu, D):
+    """Hidden sizes of timm ViTs beyond tiny / small / base / large (SO400M 1152, ViT-H 1280, ViT-g 1408, ViT-G 1664, ...)."""
+    torch = torch_gpu
+    M = 37
+    rng = np.random.default_rng(D)
+    x = (rng.standard_normal((M, D)) * 0.7 + 0.1).astype(np.float32)
+    w = (1 + 0.02 * rng.standard_normal(D)).astype(np.float32)
+    b = (0.02 * rng.standard_normal(D)).astype(np.float32)
+    ref = oracle.layernorm(x, w, b, 1e-6)
+    dx, dw, db = (torch.from_numpy(a).cuda() for a in (x, w, b))
+    y = torch.empty((M, D), dtype=torch.float16, device="cuda")
+    binding.check(binding.lib().vitx_op_layernorm(binding.F16, dx.data_ptr(), dw.data_ptr(), db.data_ptr(), y.data_ptr(), M, D, 1e-6, None))
+    torch.cuda.synchronize()
+    got = y.float().cpu().numpy()
+    ref16 = ref.astype(np.float16).astype(np.float32)
+    assert np.abs(got - ref16).max() <= np.abs(ref).max() * 2.0 ** -10 and (got != ref16).mean() < 0.01
+
+
+@pytest.mark.parametrize("name,n", [("vit_micro_hd32_patch16_64", 5), ("vit_micro_hd96_patch16_96", 3), ("vit_mini_hd80_patch14_112", 3), ("vit_mini_hd72_patch14_112", 3)])
 def test_forward_other_head_dims_vs_oracle(pkg, binding, oracle, torch_gpu, name, n):
     torch = torch_gpu
     path = pkg.synth.cached_synthetic(name, head_scale=4.0)
@@ -75,4 +94,18 @@ def test_forward_other_head_dims_vs_oracle(pkg, binding, oracle, torch_gpu, name
         ctx.close()
         assert np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-4
         assert np.abs(probs - ref_probs).max() <= tol
+    m.close()
+
+
+def test_forward_ragged_width_large_batch_equals_small_batch(pkg, binding, torch_gpu):
+    """1152 columns are 4.5 of the 256-column tiles: at a batch that takes the wide persistent GEMMs the last column tile is ragged (the
+    per-element epilogue path) and the LayerNorms are not fused (4.5 tiles); an image's probabilities must not depend on the batch."""
+    name = "vit_mini_hd72_patch14_112"
+    path = pkg.synth.cached_synthetic(name, head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(150, 112, seed=5))
+    m = binding.Model(path)
+    for dt in (binding.F16, binding.BF16):
+        big = binding.Context(m, 0, 150, dt); pb = big.forward(imgs); big.close()
+        small = binding.Context(m, 0, 3, dt); ps = small.forward(imgs[:3]); small.close()
+        assert np.isfinite(pb).all() and np.array_equal(pb[:3], ps)
     m.close()

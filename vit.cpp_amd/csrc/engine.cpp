@@ -312,7 +312,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
         set_error("vitx_ctx_create: attention needs a head_dim that is a multiple of 8 up to 128 (this model: %d) and at least one token (%d tokens, img_size %d, patch_size %d)", c->D / c->H, c->N, c->S, c->P);
         return VITX_ERR_UNSUPPORTED;
     }
-    if (!layernorm_supports(c->D)) { set_error("vitx_ctx_create: hidden_size %d has no LayerNorm instantiation (64, 128, 192, 256, 384, 512, 768, 1024, 1280, 1536)", c->D); return VITX_ERR_UNSUPPORTED; }
+    if (!layernorm_supports(c->D)) { set_error("vitx_ctx_create: hidden_size %d has no LayerNorm instantiation (64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280, 1408, 1536, 1664, 2048)", c->D); return VITX_ERR_UNSUPPORTED; }
     c->tune = tuning_for_device(device);
     if (!c->tune) { set_error("vitx_ctx_create: kernel bring-up on device %d failed: %s", device, hipGetErrorString(hipGetLastError())); return VITX_ERR_HIP; }
     c->split_first = opt.split_first;

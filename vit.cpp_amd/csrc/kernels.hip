@@ -354,13 +354,16 @@ static hipError_t launch_layernorm_t(const float *x, long ldx, const float *w, c
     switch (D) {
         VITX_LN_CASE(64, 1, 1) VITX_LN_CASE(128, 2, 1) VITX_LN_CASE(192, 1, 3) VITX_LN_CASE(256, 4, 1) VITX_LN_CASE(384, 2, 3)
         VITX_LN_CASE(512, 4, 2) VITX_LN_CASE(768, 4, 3) VITX_LN_CASE(1024, 4, 4) VITX_LN_CASE(1280, 4, 5) VITX_LN_CASE(1536, 4, 6)
+        // widths of other timm ViTs (SO400M 1152, ViT-g 1408, ViT-G 1664, ...) and of small test models
+        VITX_LN_CASE(320, 1, 5) VITX_LN_CASE(448, 1, 7) VITX_LN_CASE(576, 1, 9) VITX_LN_CASE(640, 2, 5) VITX_LN_CASE(896, 2, 7)
+        VITX_LN_CASE(1152, 2, 9) VITX_LN_CASE(1408, 2, 11) VITX_LN_CASE(1664, 2, 13) VITX_LN_CASE(2048, 4, 8)
     default: return hipErrorInvalidValue;
     }
 #undef VITX_LN_CASE
     return hipGetLastError();
 }
 bool layernorm_supports(int D) {
-    switch (D) { case 64: case 128: case 192: case 256: case 384: case 512: case 768: case 1024: case 1280: case 1536: return true; default: return false; }
+    switch (D) { case 64: case 128: case 192: case 256: case 320: case 384: case 448: case 512: case 576: case 640: case 768: case 896: case 1024: case 1152: case 1280: case 1408: case 1536: case 1664: case 2048: return true; default: return false; }
 }
 hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream, int group, long gstride) {
     if (group < 1) return hipErrorInvalidValue;

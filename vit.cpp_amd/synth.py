@@ -25,6 +25,7 @@ CONFIGS = {
     "vit_micro_hd32_patch16_64": (128, 2, 4, 10, 16, 64),  # test-only toys with head dims other than 64 (the generic attention kernel): 32,
     "vit_micro_hd96_patch16_96": (192, 2, 2, 10, 16, 96),  #   96 (N = 37),
     "vit_mini_hd80_patch14_112": (1280, 2, 16, 10, 14, 112),   # 80 with ViT-H/14's widths (patch 14: N = 65)
+    "vit_mini_hd72_patch14_112": (1152, 2, 16, 10, 14, 112),   # 72 with SO400M's widths (1152 is not a multiple of the 256-column GEMM tiles)
     "vit_base_patch8_224": (768, 12, 12, 1000, 8, 224),    # the reference's default hparams (vit.h:22-28)
     "vit_tiny_patch16_224": (192, 12, 3, 1000, 16, 224),
     "vit_small_patch16_224": (384, 12, 6, 1000, 16, 224),
