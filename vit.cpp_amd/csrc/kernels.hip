@@ -172,7 +172,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream, 
 //   * >= 128 tiles of 256x256 and K % 128 == 0: the ping-pong persistent kernel (gemm_pp.hip);
 //   * otherwise 128x256 ring tiles, or the skinny 64x128 ring kernel when those would leave half of the CUs idle
 //     (a handful of images: same K order per element, so results stay bit-identical across batch sizes);
-//   * anything the ring kernels cannot tile: the v1 128x128 kernel.
+//   * a column count that is a multiple of 128 but not of 256: the skinny ring tiles at any row count.
 static int wide_ring_cfg(const GemmArgs &a) { return gemm_ring_supports(a, 945) ? 945 : 445; }
 
 // Persistent grid of the ping-pong kernel.  Tiles are dealt round-robin, so with one workgroup per CU a partial last round
@@ -244,8 +244,10 @@ hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, h
     cfg = 245;
     if ((long)(a.M / 128) * (a.N_pad / 256) < t.skinny_tiles && gemm_ring_supports(a, 122)) cfg = 122;
     if (gemm_ring_supports(a, cfg)) return launch_gemm_ring(t, dtype, epi, a, cfg, stream);
-    if (a.M % GBM || a.N_pad % GBN || a.K % GBK) return hipErrorInvalidValue;
-    return dtype == DT_F16 ? launch_gemm_t<_Float16>(epi, a, stream, false) : launch_gemm_t<__bf16>(epi, a, stream, false);
+    // a column count that is a multiple of 128 but not of 256: the 64 x 128 ring tiles at any row count (the v1 128 x 128 kernel used to
+    // take these; it now exists only in its q4_0 form, launch_gemm_q4)
+    if (gemm_ring_supports(a, 122)) return launch_gemm_ring(t, dtype, epi, a, 122, stream);
+    return hipErrorInvalidValue;
 }
 
 bool gemm_q4_supports(const GemmArgs &a) { return a.Wscale && a.M > 0 && a.M % GBM == 0 && a.N_pad % GBN == 0 && a.K % GBK == 0; }
@@ -1268,7 +1270,6 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
         for (int epi = 0; epi <= EPI_PATCH; ++epi) {
             for (int cfg : {945, 445, 245, 122}) if ((e = launch_gemm_ring(t, dt, epi, none, cfg, nullptr, true)) != hipSuccess) return e;
             if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
-            if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16>(epi, none, nullptr, true) : launch_gemm_t<__bf16>(epi, none, nullptr, true))) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16, true>(epi, none, nullptr, true) : launch_gemm_t<__bf16, true>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
         if (dt == 0 && (e = launch_patch_embed(0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, true)) != hipSuccess) return e;
