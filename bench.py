@@ -374,6 +374,25 @@ def main():
             with SmiSampler(local_rank) as smi:
                 rate, ms = quick_rate(ctx, B, imgs, probs, n_sus, warm=0)
             out["sustained"] = {"value": round(rate, 1), "unit": "images/s", "ms_per_step": round(ms, 4), "steps": n_sus, "seconds": round(n_sus * ms * 1e-3, 2), "rocm_smi": smi.summary()}
+            # (1b) serving throughput with TWO forwards in flight: two contexts without the internal sub-batch split, whole batches from two
+            # caller streams (tools/two_in_flight.py; the same kernels at twice the rows per launch, results bit-identical) -- NOT `value`
+            try:
+                pair = [binding.Context(model, device=local_rank, max_batch=B, dtype=dt, streams=1) for _ in range(2)]
+                ref_probs_timed = probs.clone()       # what the timed context (two sub-batches) wrote for the same images
+                pp_ = [torch.empty_like(probs), torch.empty_like(probs)]
+                sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+                def run_pair(n):
+                    for i in range(n): pair[i & 1].forward_device(imgs.data_ptr(), B, pp_[i & 1].data_ptr(), 0, sts[i & 1].cuda_stream)
+                run_pair(6); torch.cuda.synchronize()
+                n2 = max(20, 2 * (args.steps // 2))
+                t0 = time.perf_counter(); run_pair(n2); torch.cuda.synchronize(); el = time.perf_counter() - t0
+                out["two_forwards_in_flight"] = {"value": round(n2 * B / el, 1), "unit": "images/s", "ms_per_forward": round(el / n2 * 1e3, 4), "forwards": n2,
+                                                 "bit_identical_to_timed_schedule": bool(torch.equal(pp_[0], ref_probs_timed) and torch.equal(pp_[1], ref_probs_timed)),
+                                                 "what": "2 contexts (streams=1), alternate forwards on 2 caller streams; each forward = one batch of the timed size"}
+                for c2 in pair: c2.close()
+                del pp_
+            except Exception as e:
+                out["two_forwards_in_flight"] = {"error": str(e)}
             # (2) the parity mode (fp16 operands: the reference's rounding points) on the same batch
             if args.dtype == "bf16":
                 c16 = binding.Context(model, device=local_rank, max_batch=B, dtype=binding.F16)

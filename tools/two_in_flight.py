@@ -1,0 +1,40 @@
+"""Throughput with TWO forwards in flight: two contexts without an internal sub-batch split (streams = 1), each fed a whole batch from its
+own caller stream, against one context that splits every batch into two sub-batches on two streams (the default).
+    python tools/two_in_flight.py [--model M] [--batch B] [--rounds R] [--steps S]
+Same images/s accounting for both: forwards completed * batch / wall time; rounds are interleaved in one process."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import _pkg; pkg = _pkg.load()
+from vitcpp_amd import binding as B
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="vit_base_patch16_224"); ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--dtype", default="bf16"); ap.add_argument("--rounds", type=int, default=4); ap.add_argument("--steps", type=int, default=20)
+a = ap.parse_args()
+path = pkg.synth.cached_synthetic(a.model, head_scale=8.0)
+hp = pkg.synth.hparams_for(a.model)
+m = B.Model(path)
+dt = B.F16 if a.dtype == "f16" else B.BF16
+imgs = [torch.randn((a.batch, hp.img_size, hp.img_size, 3), device="cuda") for _ in range(2)]
+probs = [torch.empty((a.batch, hp.num_classes), device="cuda") for _ in range(2)]
+sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+split = B.Context(m, 0, a.batch, dt)
+pair = [B.Context(m, 0, a.batch, dt, streams=1), B.Context(m, 0, a.batch, dt, streams=1)]
+def run_split(n):
+    for _ in range(n): split.forward_device(imgs[0].data_ptr(), a.batch, probs[0].data_ptr(), 0, sts[0].cuda_stream)
+def run_pair(n):
+    for i in range(n): pair[i & 1].forward_device(imgs[i & 1].data_ptr(), a.batch, probs[i & 1].data_ptr(), 0, sts[i & 1].cuda_stream)
+run_split(3); run_pair(4); torch.cuda.synchronize()
+res = {"one context, two sub-batches": [], "two contexts, two forwards in flight": []}
+for r in range(a.rounds):
+    for name, fn in (("one context, two sub-batches", run_split), ("two contexts, two forwards in flight", run_pair)):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(a.steps); torch.cuda.synchronize()
+        res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
+for name, ts in res.items():
+    ts.sort(); med = ts[len(ts) // 2]
+    print(f"{a.model} b{a.batch} {a.dtype}  {name:40s} {med:.3f} ms per forward (min {ts[0]:.3f} max {ts[-1]:.3f})  {a.batch / med * 1e3:.0f} img/s")
+# the two schedules compute the same thing
+split.forward_device(imgs[1].data_ptr(), a.batch, probs[0].data_ptr(), 0, sts[0].cuda_stream); torch.cuda.synchronize(); ref = probs[0].clone()
+pair[1].forward_device(imgs[1].data_ptr(), a.batch, probs[1].data_ptr(), 0, sts[1].cuda_stream); torch.cuda.synchronize()
+print("bit-identical probabilities:", torch.equal(ref, probs[1]))
