@@ -56,3 +56,19 @@ def predict_sharded(forward_local: Callable, images, group=None):
     n_total = images.shape[0]
     lo, hi = shard_bounds(n_total, world, rank)
     return gather_probs(forward_local(images[lo:hi]), n_total, group)
+
+
+def gather_probs_async(local_probs, n_total: int, group=None):
+    """The same collective without making the caller's stream wait for it: returns (gathered, work).  The collective is ordered after
+    everything already enqueued on the current stream (it reads `local_probs`), the caller's stream goes on -- e.g. with the next batch's
+    forward into ANOTHER probability buffer -- and `work.wait()` orders the current stream behind the collective when the result (or the
+    right to overwrite `local_probs`) is needed.  Ragged shards take the synchronous path (work = None)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if n_total % world:
+        return gather_probs(local_probs, n_total, group), None
+    out = torch.empty((n_total, local_probs.shape[1]), dtype=local_probs.dtype, device=local_probs.device)
+    work = dist.all_gather_into_tensor(out, local_probs.contiguous(), group=group, async_op=True)
+    return out, work
+
