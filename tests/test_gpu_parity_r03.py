@@ -299,3 +299,34 @@ def test_forward_ln_fallback_fixed_by_the_consumer_gemm(pkg, binding, torch_gpu,
         assert (fb > 0) == (key == "forced"), (key, fb)
         ctx.close(); model.close()
     assert torch.isfinite(outs["forced"]).all() and torch.equal(outs["plain"], outs["forced"])
+
+
+def test_two_forwards_in_flight_equal_the_split_schedule(pkg, binding, torch_gpu):
+    """two contexts without the sub-batch split, fed alternately from two caller streams, keep two whole forwards in
+    flight.  Each must return exactly what one context with the default two-sub-batch schedule returns for the same images, however the two
+    interleave on the GPU (the LayerNorm-fusing GEMMs of both contexts poll their own statistics buffers)."""
+    torch = torch_gpu
+    name, n = "vit_base_patch16_224", 256
+    path = pkg.synth.cached_synthetic(name, head_scale=8.0)
+    m = binding.Model(path)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    imgs = [torch.randn((n, 224, 224, 3), device="cuda", generator=g) for _ in range(2)]
+    ref_ctx = binding.Context(m, 0, n, binding.BF16)
+    refs = []
+    for im in imgs:
+        p = torch.empty((n, 1000), device="cuda")
+        ref_ctx.forward_device(im.data_ptr(), n, p.data_ptr(), 0, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        refs.append(p)
+    ref_ctx.close()
+    pair = [binding.Context(m, 0, n, binding.BF16, streams=1) for _ in range(2)]
+    sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty((n, 1000), device="cuda") for _ in range(2)]
+    for it in range(6):
+        for k in range(2):
+            pair[k].forward_device(imgs[k].data_ptr(), n, outs[k].data_ptr(), 0, sts[k].cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1]), f"iteration {it}"
+        outs[0].zero_(); outs[1].zero_()
+    assert pair[0].ln_fallbacks() >= 0
+    for c in pair: c.close()
+    m.close()
