@@ -330,3 +330,20 @@ def test_two_forwards_in_flight_equal_the_split_schedule(pkg, binding, torch_gpu
     assert pair[0].ln_fallbacks() >= 0
     for c in pair: c.close()
     m.close()
+
+
+@pytest.mark.parametrize("n_img,N,H", [(1, 4097, 2), (2, 2305, 1)])
+def test_attention_thousands_of_tokens(binding, torch_gpu, n_img, N, H):
+    """Any token count means any: 4097 tokens = a 1024 x 1024 input at patch 16 (the pipelined two-pass kernel streams the keys; nothing is sized
+    by N).  Against a float32 torch reference on the same fp16 / bf16 inputs."""
+    torch = torch_gpu
+    D = H * 64
+    g = torch.Generator(device="cuda").manual_seed(N)
+    for dt, tdt, tol in ((binding.F16, torch.float16, 5e-4), (binding.BF16, torch.bfloat16, 4e-3)):
+        qkv = (torch.randn((n_img * N, 3 * D), device="cuda", generator=g) * 0.8).to(tdt)
+        out = torch.full((n_img * N, D), float("nan"), device="cuda", dtype=tdt)
+        binding.check(binding.lib().vitx_op_attention(dt, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, None))
+        torch.cuda.synchronize()
+        q, k, v = qkv.float().view(n_img, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(n_img * N, D)
+        assert torch.isfinite(out).all() and float((out.float() - ref).abs().max()) <= tol
