@@ -252,6 +252,10 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *d_a, const void *d_qs, const
                     int M, int M_real, int N, int K, void *stream);
 /* Device bytes held by the context's weight matrices (blocks for quantised tensors, 16-bit operands otherwise). */
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c);
+/* Contexts of the same loaded model on the same device, with the same operand type and quantisation mode, share ONE device copy of the
+ * weights (uploaded by the first, freed with the last: e.g. the two contexts that keep two forwards in flight).
+ * 1 when this context attached to a copy that was already there, 0 when it uploaded it. */
+int vitx_ctx_shares_weights(const vitx_ctx *c);
 /* Diagnostic: GEMM tiles whose fused LayerNorm was left to the fix-up launch since the context was created (a peer workgroup did not
  * publish its row statistics in time -- possible when two such GEMMs on the context's two streams hold each other's CUs; results are
  * the same bits either way).  Synchronises the device.  -1 on error. */

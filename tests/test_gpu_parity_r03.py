@@ -347,3 +347,36 @@ def test_attention_thousands_of_tokens(binding, torch_gpu, n_img, N, H):
         q, k, v = qkv.float().view(n_img, N, 3, H, 64).permute(2, 0, 3, 1, 4)
         ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(n_img * N, D)
         assert torch.isfinite(out).all() and float((out.float() - ref).abs().max()) <= tol
+
+
+def test_contexts_of_one_model_share_the_device_weights(pkg, binding, torch_gpu):
+    """vitx_ctx_shares_weights: the second context of a loaded model (same device, operand type, block mode) attaches to the first one's
+    device copy; the copy lives as long as any of them; other operand types / another load of the file get their own."""
+    torch = torch_gpu
+    name, n = "vit_small_patch16_224", 8
+    path = pkg.synth.cached_synthetic(name, head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(n, 224, seed=3))
+    m = binding.Model(path)
+    torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+    a = binding.Context(m, 0, n, binding.BF16)
+    free1 = torch.cuda.mem_get_info()[0]
+    b = binding.Context(m, 0, n, binding.BF16, streams=1)
+    free2 = torch.cuda.mem_get_info()[0]
+    assert not a.shares_weights() and b.shares_weights() and a.weight_bytes() == b.weight_bytes() > 0
+    assert (free1 - free2) < (free0 - free1) - a.weight_bytes() // 2          # the second context paid for scratch only
+    c16 = binding.Context(m, 0, n, binding.F16)
+    assert not c16.shares_weights()                                            # another operand type: its own copy
+    pa = a.forward(imgs)
+    a.close()                                                                  # the copy stays: b still holds it
+    pb = b.forward(imgs)
+    assert np.array_equal(pa, pb)
+    d = binding.Context(m, 0, n, binding.BF16)
+    assert d.shares_weights()
+    assert np.array_equal(d.forward(imgs), pa)
+    b.close(); d.close(); c16.close()
+    e = binding.Context(m, 0, n, binding.BF16)                                 # every holder is gone: uploaded again
+    assert not e.shares_weights() and np.array_equal(e.forward(imgs), pa)
+    m2 = binding.Model(path)                                                   # another load of the same file is another model
+    f = binding.Context(m2, 0, n, binding.BF16)
+    assert not f.shares_weights()
+    e.close(); f.close(); m.close(); m2.close()

@@ -28,7 +28,7 @@ EXPORTS = [
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_image_load", "vitx_image_decode", "vitx_image_free", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
-    "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
+    "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_ctx_shares_weights", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
     "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
 
@@ -114,6 +114,7 @@ def lib():
         L.vitx_op_dequant.argtypes = [ip, ip, vp, vp, vp, ip, ip, ip, vp]
         L.vitx_op_gemm_q4.argtypes = [ip, ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, vp]
         L.vitx_ctx_weight_bytes.restype = C.c_size_t; L.vitx_ctx_weight_bytes.argtypes = [vp]
+        L.vitx_ctx_shares_weights.restype = C.c_int; L.vitx_ctx_shares_weights.argtypes = [vp]
         L.vitx_ctx_ln_fallbacks.restype = C.c_longlong; L.vitx_ctx_ln_fallbacks.argtypes = [vp]
         L.vitx_ctx_stream_retries.argtypes = [vp]
         L.vitx_op_gemm_ln.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, C.c_float, ip, ip, C.POINTER(ip), vp]
@@ -299,6 +300,10 @@ class Context:
     def weight_bytes(self) -> int:
         """Device bytes held by the weight matrices (quantised tensors stay in block form: 4.5 ... 8.5 bits per weight)."""
         return int(lib().vitx_ctx_weight_bytes(self._h))
+
+    def shares_weights(self) -> bool:
+        """True when this context attached to a device copy of the weights another context of the same model had uploaded."""
+        return bool(lib().vitx_ctx_shares_weights(self._h))
 
     def ln_fallbacks(self) -> int:
         """GEMM tiles whose fused LayerNorm was left to the fix-up launch since the context was created (vitx_ctx_ln_fallbacks)."""

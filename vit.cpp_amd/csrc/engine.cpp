@@ -12,9 +12,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "kernels.h"
@@ -69,8 +72,21 @@ struct vitx_ctx {
     int skip = 0;                        // VITX_SKIP (upper-bound experiments; results are garbage): 1 = no attention, 2 = no per-layer LayerNorm
 #endif
     hipStream_t stream = nullptr;
-    std::vector<void *> allocs;
-    // weights
+    std::vector<void *> allocs;          // scratch of THIS context
+    // weights: device copies are shared by every context of the same loaded model, device, operand type and quantisation mode
+    // (WeightSet below; e.g. the two contexts of INTEGRATION.md's "two forwards in flight"): uploaded by the first, freed with the last
+    struct WeightSet {
+        int device = 0;
+        std::vector<void *> allocs;
+        float *cls = nullptr, *pos = nullptr, *pe_b = nullptr, *norm_w = nullptr, *norm_b = nullptr, *head_b = nullptr;
+        void *pe_w = nullptr, *head_w = nullptr;
+        QuantW head_q;
+        std::vector<LayerW> layers;
+        size_t weight_bytes = 0;
+        ~WeightSet() { (void)hipSetDevice(device); for (void *p : allocs) (void)hipFree(p); }
+    };
+    std::shared_ptr<WeightSet> wset;
+    bool weights_shared = false;         // this context found the set already uploaded (vitx_ctx_shares_weights)
     float *cls = nullptr, *pos = nullptr, *pe_b = nullptr, *norm_w = nullptr, *norm_b = nullptr, *head_b = nullptr;
     void *pe_w = nullptr, *head_w = nullptr;
     QuantW head_q;
@@ -158,6 +174,11 @@ struct vitx_ctx {
         if (zero) HIP_TRY(hipMemset(*p, 0, bytes ? bytes : 16));
         return VITX_OK;
     }
+    int wmalloc(void **p, size_t bytes) {      // weight storage: owned by the shared set
+        HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+        wset->allocs.push_back(*p);
+        return VITX_OK;
+    }
     hipEvent_t next_event() {
         if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
         return ev_pool[ev_used++];
@@ -171,7 +192,7 @@ int upload_f32(vitx_ctx *c, const HostTensor *t, float **out, size_t n_pad = 0) 
     std::vector<float> h((size_t)t->nelements());
     t->decode_f32(h.data());
     if (n_pad > h.size()) h.resize(n_pad, 0.0f);
-    int rc = c->dmalloc((void **)out, h.size() * 4, false);
+    int rc = c->wmalloc((void **)out, h.size() * 4);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(*out, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     return VITX_OK;
@@ -193,7 +214,7 @@ int upload_matrix(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad,
                 h[(size_t)n * k_pad + k] = c->dtype == VITX_F16 ? f32_to_f16_bits(f[(size_t)n * K + k]) : f32_to_bf16_bits(f[(size_t)n * K + k]);
     }
     if (patch_P > 0) { std::vector<uint16_t> hp(h.size(), 0); patch_embed_permute_k(h.data(), hp.data(), Nrows, patch_Cin, patch_P, k_pad); h.swap(hp); }
-    int rc = c->dmalloc(out, h.size() * 2, false);
+    int rc = c->wmalloc(out, h.size() * 2);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(*out, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     c->weight_bytes += h.size() * 2;
@@ -221,14 +242,14 @@ int upload_quant(vitx_ctx *c, const HostTensor *t, int Nrows, int K, int n_pad, 
         std::vector<uint16_t> ds((size_t)n_pad * nbk, 0);
         const uint8_t *src = t->raw.data();
         for (size_t b = 0; b < (size_t)Nrows * nbk; ++b) { memcpy(&ds[b], src + b * 18, 2); memcpy(&qs[b * 16], src + b * 18 + 2, 16); }
-        if ((rc = c->dmalloc(&q->blocks, qs.size(), false))) return rc;
-        if ((rc = c->dmalloc((void **)&q->scales, ds.size() * 2, false))) return rc;
+        if ((rc = c->wmalloc(&q->blocks, qs.size()))) return rc;
+        if ((rc = c->wmalloc((void **)&q->scales, ds.size() * 2))) return rc;
         HIP_TRY(hipMemcpy(q->blocks, qs.data(), qs.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(q->scales, ds.data(), ds.size() * 2, hipMemcpyHostToDevice));
         c->weight_bytes += qs.size() + ds.size() * 2;
     } else {
         const size_t bytes = (size_t)Nrows * nbk * bb;
-        if ((rc = c->dmalloc(&q->blocks, bytes, false))) return rc;
+        if ((rc = c->wmalloc(&q->blocks, bytes))) return rc;
         HIP_TRY(hipMemcpy(q->blocks, t->raw.data(), bytes, hipMemcpyHostToDevice));
         c->weight_bytes += bytes;
     }
@@ -330,6 +351,19 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     const int D = c->D, tn = c->tn;
     int rc;
     auto T = [&](const std::string &n) { return m->find(n); };
+    // device copies of the weights: one set per (loaded model, device, operand type, block mode), shared by every context that asks for it
+    static std::mutex wreg_mu;
+    static std::map<std::tuple<uint64_t, int, int, int>, std::weak_ptr<vitx_ctx::WeightSet>> wreg;
+    const auto wkey = std::make_tuple(m->uid, device, dtype, c->quant_on_device ? 1 : 0);
+    std::unique_lock<std::mutex> wlock(wreg_mu);           // held through the upload: a second context of the same model waits for the first
+    for (auto it = wreg.begin(); it != wreg.end();) it = it->second.expired() ? wreg.erase(it) : std::next(it);      // sets whose last context is gone
+    if (auto have = wreg[wkey].lock()) {
+        c->wset = have; c->weights_shared = true;
+    } else {
+        c->wset = std::make_shared<vitx_ctx::WeightSet>();
+        c->wset->device = device;
+    }
+    if (!c->weights_shared) {
     if ((rc = upload_f32(c.get(), T("cls_token"), &c->cls))) return rc;
     if ((rc = upload_f32(c.get(), T("pos_embed"), &c->pos))) return rc;
     if ((rc = upload_f32(c.get(), T("patch_embed.proj.bias"), &c->pe_b, round_up(D, tn)))) return rc;
@@ -355,6 +389,16 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     if ((rc = upload_f32(c.get(), T("norm.bias"), &c->norm_b))) return rc;
     if ((rc = upload_f32(c.get(), T("head.bias"), &c->head_b, c->C_pad))) return rc;
     if ((rc = upload_weight(c.get(), T("head.weight"), c->C, D, c->C_pad, &c->head_w, &c->head_q))) return rc;
+        vitx_ctx::WeightSet &w = *c->wset;
+        w.cls = c->cls; w.pos = c->pos; w.pe_b = c->pe_b; w.norm_w = c->norm_w; w.norm_b = c->norm_b; w.head_b = c->head_b;
+        w.pe_w = c->pe_w; w.head_w = c->head_w; w.head_q = c->head_q; w.layers = c->layers; w.weight_bytes = c->weight_bytes;
+        wreg[wkey] = c->wset;
+    } else {
+        const vitx_ctx::WeightSet &w = *c->wset;
+        c->cls = w.cls; c->pos = w.pos; c->pe_b = w.pe_b; c->norm_w = w.norm_w; c->norm_b = w.norm_b; c->head_b = w.head_b;
+        c->pe_w = w.pe_w; c->head_w = w.head_w; c->head_q = w.head_q; c->layers = w.layers; c->weight_bytes = w.weight_bytes;
+    }
+    wlock.unlock();
 
     // sub-batch slices (vitx_ctx_options::streams; 1 = single stream).  Small contexts stay single-slice.
     int ns = opt.streams > 0 ? opt.streams : 2;
@@ -884,6 +928,7 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *a, const void *qs, const voi
     return VITX_OK;
 }
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c) { return c ? c->weight_bytes : 0; }
+int vitx_ctx_shares_weights(const vitx_ctx *c) { return c && c->weights_shared ? 1 : 0; }
 int vitx_ctx_stream_retries(const vitx_ctx *c) { return c ? c->stream_retries : -1; }
 long long vitx_ctx_ln_fallbacks(vitx_ctx *c) {
     if (!c) return -1;
