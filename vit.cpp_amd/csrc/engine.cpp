@@ -432,6 +432,9 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
         }
         if (c->head_q.blocks && (rc = c->dmalloc(&sl.Wq_head, (size_t)c->head_q.n_pad * c->head_q.K * 2, false))) return rc;
         sl.tune = *c->tune;
+#ifdef VITX_LAB
+        if (const char *e = getenv("VITX_SLICE_CU")) { if (ns > 1 && atoi(e) > 0) sl.tune.n_cu = atoi(e); }      // persistent grids of each sub-batch capped (experiment)
+#endif
         if (ns > 1 && i > 0) {
             // Slice 0 runs on the CALLER's stream, slices 1.. on internal HIGH-priority streams.  The runtime multiplexes all streams of one
             // priority onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by default), round-robin in creation order; a hardware queue
