@@ -147,6 +147,10 @@ int vitx_ctx_max_batch(const vitx_ctx *c);
  * file ([n][25][num_classes], row t = token t of the image; decode with vitx_vitstr_decode).  Images are then ONE grey channel:
  * [img_size][img_size] f32, as vitx_preprocess_vitstr_u8 emits. */
 int vitx_ctx_out_rows(const vitx_ctx *c);
+/* How a forward of n images is cut into contiguous sub-batches (one per internal stream): images[i] = size of sub-batch i, in image
+ * order; returns the number of sub-batches (1 when the batch runs on one stream), 0 on a bad argument.  Results never depend on the
+ * cut; the parity tests use it to pick the images on either side of every stream boundary. */
+int vitx_ctx_split(const vitx_ctx *c, int n, int32_t *images, int max_parts);
 
 /* Forward pass (replaces vit_encode_image + the compute half of vit_predict,
  * vit.cpp:718-941, 1028-1040) on n <= max_batch images.
@@ -155,7 +159,9 @@ int vitx_ctx_out_rows(const vitx_ctx *c);
  *   logits   : optional (may be NULL), pre-softmax
  * vitx_forward takes host pointers (copies in/out and synchronises);
  * vitx_forward_device takes device pointers and only enqueues on `stream`
- * (a hipStream_t, NULL = the context's own stream). */
+ * (a hipStream_t, NULL = the context's own stream).  One exception: the FIRST multi-stream forward of a context (>= 16 images)
+ * synchronises the host once for ~0.2 ms while it measures whether its internal sub-batch stream really runs beside the caller's
+ * stream (vitx_ctx_stream_retries); every later call, on this or any other caller stream, only enqueues. */
 int vitx_forward(vitx_ctx *c, const float *imgs_hwc, int n, float *probs, float *logits);
 int vitx_forward_device(vitx_ctx *c, const void *d_imgs_hwc, int n, void *d_probs, void *d_logits, void *stream);
 int vitx_ctx_synchronize(vitx_ctx *c);

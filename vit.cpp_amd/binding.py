@@ -29,7 +29,7 @@ EXPORTS = [
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_ctx_shares_weights", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
-    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
+    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
 
 
@@ -120,6 +120,7 @@ def lib():
         L.vitx_op_gemm_ln.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, C.c_float, ip, ip, C.POINTER(ip), vp]
         L.vitx_probe_mfma.argtypes = [ip, ip, ip, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.vitx_model_in_channels.argtypes = [vp]; L.vitx_model_seq_len.argtypes = [vp]; L.vitx_ctx_out_rows.argtypes = [vp]
+        L.vitx_ctx_split.argtypes = [vp, ip, C.POINTER(C.c_int32), ip]
         L.vitx_preprocess_vitstr_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, C.POINTER(C.c_float)]
         L.vitx_vitstr_decode.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(ip), C.POINTER(C.c_double)]
         _lib = L
@@ -296,6 +297,22 @@ class Context:
 
     def synchronize(self) -> None:
         check(lib().vitx_ctx_synchronize(self._h), "vitx_ctx_synchronize")
+
+    def split(self, n: int) -> List[int]:
+        """Sizes of the contiguous sub-batches a forward of n images is cut into (vitx_ctx_split); [n] on one stream."""
+        m = (C.c_int32 * 4)()
+        k = lib().vitx_ctx_split(self._h, n, m, 4)
+        if k <= 0:
+            raise VitxError(f"vitx_ctx_split({n}) failed")
+        return [int(m[i]) for i in range(k)]
+
+    def boundary_rows(self, n: int) -> List[int]:
+        """Image ids on either side of every sub-batch boundary of an n-image forward, plus both ends of the batch."""
+        ids, off = {0, min(1, n - 1), max(0, n - 2), n - 1}, 0
+        for sz in self.split(n)[:-1]:
+            off += sz
+            ids.update({off - 1, off})
+        return sorted(i for i in ids if 0 <= i < n)
 
     def weight_bytes(self) -> int:
         """Device bytes held by the weight matrices (quantised tensors stay in block form: 4.5 ... 8.5 bits per weight)."""

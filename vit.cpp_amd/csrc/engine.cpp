@@ -83,7 +83,11 @@ struct vitx_ctx {
         QuantW head_q;
         std::vector<LayerW> layers;
         size_t weight_bytes = 0;
-        ~WeightSet() { (void)hipSetDevice(device); for (void *p : allocs) (void)hipFree(p); }
+        ~WeightSet() {       // may run on any thread (the last context of the set): leave the caller's current device as it was
+            int cur = -1; (void)hipGetDevice(&cur);
+            (void)hipSetDevice(device); for (void *p : allocs) (void)hipFree(p);
+            if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        }
     };
     std::shared_ptr<WeightSet> wset;
     bool weights_shared = false;         // this context found the set already uploaded (vitx_ctx_shares_weights)
@@ -128,8 +132,7 @@ struct vitx_ctx {
     int nslices = 1;
     std::vector<Slice> slices;
     hipEvent_t fork = nullptr;
-    hipStream_t probed_stream = nullptr;  // caller stream the internal streams were last checked against (ensure_concurrent)
-    bool probed = false;
+    std::vector<hipStream_t> probed_streams;   // caller streams the internal streams were already checked against (ensure_concurrent): never re-probed
     int stream_retries = 0;               // internal streams re-created because they did not run beside the caller's stream
     hipEvent_t probe_a = nullptr, probe_b = nullptr;
     float *img = nullptr;        // [max_batch][S][S][3] staging for the host entry point
@@ -460,6 +463,16 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
 
 void vitx_ctx_free(vitx_ctx *c) { delete c; }
 int vitx_ctx_max_batch(const vitx_ctx *c) { return c ? c->max_batch : 0; }
+static void split_batch(const vitx_ctx *c, int n, int ns, int *m);
+int vitx_ctx_split(const vitx_ctx *c, int n, int32_t *images, int max_parts) {
+    if (!c || !images || max_parts <= 0 || n <= 0 || n > c->max_batch) return 0;
+    const int ns = (c->nslices > 1 && n >= 8 * c->nslices) ? c->nslices : 1;
+    if (ns > max_parts) return 0;
+    int m[4] = {n, 0, 0, 0};
+    if (ns > 1) split_batch(c, n, ns, m);
+    for (int i = 0; i < ns; ++i) images[i] = m[i];
+    return ns;
+}
 int vitx_ctx_out_rows(const vitx_ctx *c) { return c ? c->R : 0; }
 
 static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const void *d_imgs, int first_img, int n, void *d_probs, void *d_logits) {
@@ -566,7 +579,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
                        fix_u.todo ? &fix_u : nullptr))) return rc;
         {   // attention (vit.cpp:826-866)
-            ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * 64, (double)M_real * 4 * D * eb);
+            ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * (D / c->H), (double)M_real * 4 * D * eb);
             if (!(skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
         }
         // output projection + residual (vit.cpp:868-873), then norm2 (vit.cpp:881-885) -> U2
@@ -694,7 +707,8 @@ static int forward_graph(vitx_ctx *c, hipStream_t st, const void *d_imgs, int n,
 // so it is measured: a 40 us do-nothing kernel on each stream, forked and joined like a forward; ~40 us = concurrent, ~80 us = serialised.
 // For a serialised internal stream up to 8 candidate streams are created and kept alive TOGETHER (a stream created after another was
 // destroyed gets the same queue back), the first one that runs beside the caller's stream is adopted, the rest are destroyed.
-// Once per (context, caller stream), ~0.2 ms, synchronous; skipped while the caller captures a graph.
+// Once per context (on the first forward of >= 16 images: the first caller stream it sees), ~0.2 ms, synchronous -- documented in vitx.h;
+// skipped while the caller captures a graph.
 static int probe_pair(vitx_ctx *c, hipStream_t st, hipStream_t s1, hipEvent_t done, float *best_ms) {
     *best_ms = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {        // the first pass also wakes the queues up
@@ -713,7 +727,11 @@ static int probe_pair(vitx_ctx *c, hipStream_t st, hipStream_t s1, hipEvent_t do
     return VITX_OK;
 }
 static int ensure_concurrent(vitx_ctx *c, hipStream_t st, int ns) {
-    if (ns < 2 || (c->probed && c->probed_stream == st)) return VITX_OK;
+    if (ns < 2 || std::find(c->probed_streams.begin(), c->probed_streams.end(), st) != c->probed_streams.end()) return VITX_OK;
+    // Only the FIRST caller stream a context sees is probed (and may get the internal streams replaced): a caller that alternates streams
+    // must not pay a synchronising probe per call, and replacing an internal stream for the second caller stream could undo what was
+    // found for the first (r03 advisor).  Later caller streams are remembered and left alone.
+    if (!c->probed_streams.empty()) { if (c->probed_streams.size() < 16) c->probed_streams.push_back(st); return VITX_OK; }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return VITX_OK; }
     if (!c->probe_a) { HIP_TRY(hipEventCreate(&c->probe_a)); HIP_TRY(hipEventCreate(&c->probe_b)); }
@@ -738,7 +756,7 @@ static int ensure_concurrent(vitx_ctx *c, hipStream_t st, int ns) {
         if (rc) return rc;
         if (pick >= 0) { (void)hipStreamDestroy(sl.stream); sl.stream = cand[pick]; }       // otherwise keep the original: nothing better exists
     }
-    c->probed = true; c->probed_stream = st;
+    c->probed_streams.push_back(st);
     return VITX_OK;
 }
 

@@ -37,6 +37,9 @@
 #ifndef PP_MAX_VGPR
 #define PP_MAX_VGPR 128
 #endif
+#ifndef PP_RESID_DEPTH
+#define PP_RESID_DEPTH 1        // passes the residual rows of the LayerNorm-fusing epilogue are requested ahead (r04 A/B: 1 = 3 = 5 = 7, profiles/r04/ab_resid_depth.txt)
+#endif
 
 namespace vitx {
 
@@ -113,7 +116,11 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
         for (int j = 0; j < 2; ++j) br[j] = *(const f32x4 *)(patch + j * 128 + lk * 16);       // bias of columns j * 32 + 4 lk .. of the wave's 64 (LDS-DMA'd during the K loop)
         pp_lds_fence();
         const int wr_row = l15 * 128, x16 = (l15 & 7) * 16;
-        u32x4 res[2][2];
+        // residual rows: loaded RD passes ahead of their use.  r04 tested the hypothesis that one pass ahead (16 KiB in flight per CU) leaves
+        // the epilogue latency-bound: depths 1 / 3 / 5 / 7 run the forward in 9.55 / 9.67 / 9.64 / 9.56 ms (interleaved, one box) -- it is not;
+        // all 240 workgroups of a round are in their epilogue at the same time and together they move 640 KB per tile at ~4.5 TB/s
+        constexpr int RD = PP_RESID_DEPTH;
+        u32x4 res[RD + 1][2];
         auto load_res = [&](int c, u32x4 (&dst)[2]) {
             const int b = c >> 1, j = c & 1;
 #pragma unroll
@@ -126,12 +133,13 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
             for (int uu = 0; uu < 2; ++uu) *(f32x4 *)(pb + (((4 * uu + g4) * 16) ^ x16)) = acc[b][2 * j + uu];
             pp_lds_fence();
         };
-        load_res(0, res[0]);
+#pragma unroll
+        for (int c = 0; c < RD; ++c) load_res(c, res[c % (RD + 1)]);
         write_pass(0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int b = c >> 1, j = c & 1;
-            if (c + 1 < 16) load_res(c + 1, res[(c + 1) & 1]);
+            if (c + RD < 16) load_res(c + RD, res[(c + RD) % (RD + 1)]);
             f32x4 d[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) d[t] = *(const f32x4 *)(patch + (c & 1) * 2048 + t * 1024 + rd_off);
@@ -139,7 +147,7 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
             if (c + 1 < 16) write_pass(c + 1);          // reads the accumulators of pass c + 1: other registers than xv(b, j, .) below
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                xv(b, j, t) = (d[t] + br[j]) + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
+                xv(b, j, t) = (d[t] + br[j]) + __builtin_bit_cast(f32x4, res[c % (RD + 1)][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
                 asm volatile("" : "+v"(xv(b, j, t)));      // materialise NOW: with its first use far below, LLVM sinks the add and keeps (spills) all 32 residual loads
             }
         }

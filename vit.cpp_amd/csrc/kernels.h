@@ -82,6 +82,7 @@ enum { ATTN_AUTO = 0, ATTN_SINGLE = 1, ATTN_FLOW = 3, ATTN_PERSIST = 4 };
 struct Tuning {
     int device = 0;
     int n_cu = 256;          // compute units of THIS device
+    int n_xcd = 8;           // XCDs (hipDeviceAttributeNumberOfXccs): the LayerNorm-fusing GEMM's peer mapping is built for exactly 8
     int gemm_cfg = -1;       // -1 automatic, 1 = the ping-pong kernel forced, else a ring configuration (445, 945, 245, 122)
     int skinny_tiles = 128;  // 64x128 tiles (cfg 122) when fewer than this many 128x256 tiles exist (r02f: 64 -> 128, batches of 4-16 images)
     int gemm_split = 0;      // 1: tail rows of a partial round re-tiled 128x256 in a second launch

@@ -197,7 +197,9 @@ static bool is_wide(const GemmArgs &a) {
 int gemm_pp_ln_grid(int n_cu, int M, int N);      // gemm_pp.hip
 int gemm_ln_grid(int n_cu, int M, int N) { return gemm_pp_ln_grid(n_cu, M, N); }
 bool gemm_ln_fusable(const Tuning &t, const GemmArgs &a) {
-    return t.gemm_cfg < 0 && !t.gemm_split && !t.pp_flags && a.M > 0 && is_wide(a) && gemm_pp_supports(a) && a.N == a.ldo && a.N == a.N_pad && a.N % 256 == 0 &&
+    // the peer mapping of pp_epilogue_ln (bid & 7 = XCD, whole row blocks per XCD) is built for the 8 XCDs of an MI355X in SPX mode: any
+    // other partitioning (CPX / a different part) takes the stand-alone LayerNorm -- same bits, no spinning on peers that are elsewhere
+    return t.n_xcd == 8 && t.n_cu % 8 == 0 && t.gemm_cfg < 0 && !t.gemm_split && !t.pp_flags && a.M > 0 && is_wide(a) && gemm_pp_supports(a) && a.N == a.ldo && a.N == a.N_pad && a.N % 256 == 0 &&
            a.N / 256 <= LN_MAX_TILES && (size_t)a.M * a.ldo * 4 < 0xf0000000u;
 }
 bool gemm_fix_capable(const Tuning &t, const GemmArgs &a) {
@@ -1295,6 +1297,7 @@ const Tuning *tuning_for_device(int device) {
     std::unique_ptr<Tuning> t(new Tuning());
     t->device = device;
     if (hipDeviceGetAttribute(&t->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || t->n_cu <= 0) t->n_cu = 256;
+    if (hipDeviceGetAttribute(&t->n_xcd, hipDeviceAttributeNumberOfXccs, device) != hipSuccess || t->n_xcd <= 0) { (void)hipGetLastError(); t->n_xcd = 0; }      // unknown: no LayerNorm fusion
 #ifdef VITX_LAB      // the laboratory build (tools/) reads its experiment switches from the environment; the product library reads none of them
     auto env_int = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
     if (const char *e = getenv("VITX_GEMM_CFG")) t->gemm_cfg = !strcmp(e, "pp") ? 1 : atoi(e);
