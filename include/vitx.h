@@ -139,6 +139,8 @@ typedef struct vitx_ctx_options {
     int32_t no_ln_fusion;     /* 1: every LayerNorm runs as its own kernel (default: norm2 / the next norm1 ride in the proj / fc2 GEMMs) */
     int32_t ln_test;          /* parity tests only: 1 = every fifth tile of a LayerNorm-fusing GEMM behaves as if a peer had timed out, 3 = and withholds its
                                  statistics (real 50 us time-outs): the consumer-side fix-up must then give the same bits */
+    int32_t f16_fast_attention; /* VITX_F16 contexts: 1 = q, k, v rounded to fp16 for the attention products (the r03 behaviour: one QKV plane, the fast
+                                 attention kernels) instead of the parity mode's f32-grade products (two fp16 planes, three MFMAs per product) */
 } vitx_ctx_options;
 int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype, const vitx_ctx_options *options, vitx_ctx **out);
 void vitx_ctx_free(vitx_ctx *c);
@@ -225,6 +227,8 @@ int vitx_op_layernorm(int dtype, const void *d_x, const void *d_w, const void *d
  *   epi 1: out dtype  = gelu_tanh(acc + bias)       (vit.cpp:889-893)
  *   epi 2: out f32    = (acc + bias) + out  in place (vit.cpp:868-873, 896-900)
  *   epi 3: out f32    = acc + bias                  (vit.cpp:927-928)
+ *   epi 5: out dtype  = TWO planes of acc + bias: hi = round(v) at out[m][n], lo = round((v - hi) * 2048) at out[M * N + m * N + n]
+ *                      (the parity mode's f32-grade q, k, v; vitx_op_gemm_ex only; `out` holds 2 * M * N elements)
  * M must be a multiple of 128 rows allocated; N, K multiples of 64. */
 int vitx_op_gemm(int dtype, int epi, const void *d_a, const void *d_w, const void *d_bias, void *d_out, int M, int N, int K, void *stream);
 /* The same with an explicit kernel family, so every production GEMM variant can be checked against a numeric reference:
@@ -275,8 +279,13 @@ int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int 
  * 3 = pipelined two-pass kernel (any N; LDS-DMA double buffering, transposed LDS reads), 4 = persistent single-pass kernel (193..224
  * tokens: one workgroup per CU walks the (image, head) items, the next item's K/V land by LDS-DMA while the current one is computed).
  * Kernels 1 and 3 give bit-identical results; kernel 4 issues v_mfma_f32_16x16x32 instead of 32x32x16 (same products, another
- * accumulation grouping: equal within f32 summation noise). */
+ * accumulation grouping: equal within f32 summation noise).
+ * kernel 5 = streaming two-pass kernel (attention_stream.hip; any N, head dim 64: v_mfma_f32_16x16x32, 64-key chunks through a 3-slot LDS-DMA ring). */
 int vitx_op_attention_ex(int dtype, int kernel, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
+/* The F16 parity mode's attention on f32 q, k, v (the reference multiplies f32 operands, vit.cpp:848,858): d_qkv_f32 [n_img * N][3 D] f32 is
+ * split into hi / lo fp16 planes (what the QKV GEMM's epi 5 emits) and every product is hi.hi + (hi.lo + lo.hi) / 2048.  d_out [n_img * N][D]
+ * fp16.  Head dim 64.  Synchronous. */
+int vitx_op_attention_f32(const float *d_qkv_f32, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* probs = softmax(logits) over num_classes with the reference's fp16 exp rounding (vit.cpp:931). */
 int vitx_op_softmax(const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);
 /* The same with the rounding type of the exp explicit (VITX_F16 = the reference's LUT semantics, VITX_BF16 = the bf16 engine). */

@@ -76,7 +76,20 @@ static void init_tables(void) {
  * 8 lanes; leftovers added in scalar.  Summation order is implementation-defined
  * in ggml; this mirrors the AVX2 build. */
 static inline float dot_f32(const float *a, const float *b, int n) {
-    if (g_dot_exact) { double s = 0.0; for (int i = 0; i < n; ++i) s += (double)a[i] * (double)b[i]; return (float)s; }
+    if (g_dot_exact) {      /* probe: double accumulation (a float x float product is exact in double); 4 x 4 lanes, then the leftovers */
+        __m256d s0 = _mm256_setzero_pd(), s1 = s0, s2 = s0, s3 = s0;
+        int i = 0;
+        for (; i + 16 <= n; i += 16) {
+            s0 = _mm256_fmadd_pd(_mm256_cvtps_pd(_mm_loadu_ps(a + i)), _mm256_cvtps_pd(_mm_loadu_ps(b + i)), s0);
+            s1 = _mm256_fmadd_pd(_mm256_cvtps_pd(_mm_loadu_ps(a + i + 4)), _mm256_cvtps_pd(_mm_loadu_ps(b + i + 4)), s1);
+            s2 = _mm256_fmadd_pd(_mm256_cvtps_pd(_mm_loadu_ps(a + i + 8)), _mm256_cvtps_pd(_mm_loadu_ps(b + i + 8)), s2);
+            s3 = _mm256_fmadd_pd(_mm256_cvtps_pd(_mm_loadu_ps(a + i + 12)), _mm256_cvtps_pd(_mm_loadu_ps(b + i + 12)), s3);
+        }
+        double t[4]; _mm256_storeu_pd(t, _mm256_add_pd(_mm256_add_pd(s0, s1), _mm256_add_pd(s2, s3)));
+        double s = (t[0] + t[1]) + (t[2] + t[3]);
+        for (; i < n; ++i) s += (double)a[i] * (double)b[i];
+        return (float)s;
+    }
     float acc[32];
     for (int j = 0; j < 32; ++j) acc[j] = 0.0f;
     const int np = n & ~31;

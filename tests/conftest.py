@@ -39,3 +39,19 @@ def torch_gpu():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible: the HIP path has no CPU fallback")
     return torch
+
+
+def boundary_rows(binding, path, n, dtype=0, **options):
+    """Image ids an n-image forward of this model is checked on: both ends of the batch and the images on either side of every
+    sub-batch stream boundary of the context the engine actually builds (vitx_ctx_split) -- r03 verdict: the hard-coded 109 / 110
+    had gone stale when the split moved to 103 + 153."""
+    model = binding.Model(path)
+    ctx = binding.Context(model, device=0, max_batch=n, dtype=dtype, **options)
+    parts, ids = ctx.split(n), ctx.boundary_rows(n)
+    ctx.close(); model.close()
+    assert sum(parts) == n and all(p > 0 for p in parts)
+    off = 0
+    for sz in parts[:-1]:
+        off += sz
+        assert off - 1 in ids and off in ids
+    return ids

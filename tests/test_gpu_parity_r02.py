@@ -225,13 +225,14 @@ def test_class_softmax_both_roundings(binding, oracle, torch_gpu, dtype_name):
 # ------------------------------------------------------------------------------------------------------------------
 # The benchmarked configuration: ViT-B/16, batch 256, two sub-batch streams
 # ------------------------------------------------------------------------------------------------------------------
-CHECK_IDS = [0, 1, 109, 110, 254, 255]        # both ends of the 110 + 146 split bench.py's context uses
+from conftest import boundary_rows      # both ends of the batch + both sides of the context's ACTUAL sub-batch boundary (vitx_ctx_split)
 
 
-def _bench_like_forward(binding, torch, path, imgs, dtype):
+def _bench_like_forward(binding, torch, path, imgs, dtype, CHECK_IDS):
     """Exactly bench.py's call: device-resident images, vitx_forward_device on a non-default torch stream."""
     model = binding.Model(path)
     ctx = binding.Context(model, device=0, max_batch=256, dtype=dtype)
+    assert ctx.boundary_rows(256) == CHECK_IDS and len(ctx.split(256)) == 2
     ctx.trace_enable(CHECK_IDS)
     d_imgs = torch.from_numpy(imgs).cuda()
     d_probs = torch.empty((256, model.num_classes), device="cuda"); d_logits = torch.empty_like(d_probs)
@@ -251,7 +252,8 @@ def test_forward_base_bs256_f16_vs_oracle(pkg, binding, oracle, torch_gpu):
     name = "vit_base_patch16_224"
     path = pkg.synth.cached_synthetic(name, head_scale=4.0)
     imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(256, 224, seed=2025))
-    probs, logits, x = _bench_like_forward(binding, torch_gpu, path, imgs, binding.F16)
+    CHECK_IDS = boundary_rows(binding, path, 256, binding.F16)
+    probs, logits, x = _bench_like_forward(binding, torch_gpu, path, imgs, binding.F16, CHECK_IDS)
     assert np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-4
     om = oracle.OracleModel(path)
     ref_logits, ref_probs, xd = om.forward(imgs[CHECK_IDS], oracle.REF, dump=True)
@@ -275,7 +277,8 @@ def test_forward_base_bs256_bf16_vs_oracle(pkg, binding, oracle, torch_gpu):
     name = "vit_base_patch16_224"
     path = pkg.synth.cached_synthetic(name, head_scale=4.0)
     imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(256, 224, seed=2025))
-    probs, logits, x = _bench_like_forward(binding, torch_gpu, path, imgs, binding.BF16)
+    CHECK_IDS = boundary_rows(binding, path, 256, binding.BF16)
+    probs, logits, x = _bench_like_forward(binding, torch_gpu, path, imgs, binding.BF16, CHECK_IDS)
     assert np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-4
     om = oracle.OracleModel(path)
     rl, rp = om.forward(imgs[CHECK_IDS], oracle.REF)

@@ -16,7 +16,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CHECK_IDS = [0, 1, 109, 110, 254, 255]        # both ends of the 110 + 146 split the context uses for 256 ViT-B images
+from conftest import boundary_rows      # rows on both sides of the context's actual sub-batch boundary
 RECORD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r03.jsonl")
 
 
@@ -53,6 +53,8 @@ def test_forward_base_bs256_q4_0_vs_oracle(pkg, binding, oracle, torch_gpu):
     path = pkg.synth.cached_synthetic(name, ftype=2, head_scale=4.0)
     imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(256, 224, seed=2025))
     om = oracle.OracleModel(path)
+    CHECK_IDS = boundary_rows(binding, path, 256, binding.F16)
+    assert CHECK_IDS == boundary_rows(binding, path, 256, binding.BF16)
     sub = imgs[CHECK_IDS]
     _, p_deq = om.forward(sub, dataclasses.replace(oracle.REF, quant_act=0))      # dequantised weights x fp16 activations: the engine's semantics
     _, p_ggml = om.forward(sub, oracle.REF)                                       # q4_0 x q8_0 integer block dots: the reference's semantics

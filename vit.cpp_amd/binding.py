@@ -19,9 +19,9 @@ LIB_PATH = os.environ.get("VITX_LIB") or os.path.join(_HERE, "libvitx.so")
 
 F16, BF16 = 0, 1
 BICUBIC, BILINEAR = 0, 1
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_BIAS_HILO = 0, 1, 2, 3, 4, 5
 GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT = 0, 1, 2          # vitx_op_gemm_ex `kernel` (or a ring configuration: 945, 445, 245, 122)
-ATTN_AUTO, ATTN_SINGLE, ATTN_FLOW, ATTN_PERSIST = 0, 1, 3, 4   # vitx_op_attention_ex `kernel`
+ATTN_AUTO, ATTN_SINGLE, ATTN_FLOW, ATTN_PERSIST, ATTN_STREAM = 0, 1, 3, 4, 5   # vitx_op_attention_ex `kernel`
 
 EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_uid", "vitx_model_hparams", "vitx_model_num_labels",
@@ -29,7 +29,7 @@ EXPORTS = [
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_ctx_shares_weights", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
-    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
+    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_op_attention_f32", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
 
 
@@ -40,7 +40,7 @@ class HParams(C.Structure):
 
 class CtxOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("streams", C.c_int32), ("graph", C.c_int32), ("quant_on_host", C.c_int32), ("q4_fused_rows", C.c_int32),
-                ("split_first", C.c_int32), ("no_ln_fusion", C.c_int32), ("ln_test", C.c_int32)]
+                ("split_first", C.c_int32), ("no_ln_fusion", C.c_int32), ("ln_test", C.c_int32), ("f16_fast_attention", C.c_int32)]
 
 
 class ProfEntry(C.Structure):
@@ -121,6 +121,7 @@ def lib():
         L.vitx_probe_mfma.argtypes = [ip, ip, ip, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.vitx_model_in_channels.argtypes = [vp]; L.vitx_model_seq_len.argtypes = [vp]; L.vitx_ctx_out_rows.argtypes = [vp]
         L.vitx_ctx_split.argtypes = [vp, ip, C.POINTER(C.c_int32), ip]
+        L.vitx_op_attention_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp]
         L.vitx_preprocess_vitstr_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, C.POINTER(C.c_float)]
         L.vitx_vitstr_decode.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(ip), C.POINTER(C.c_double)]
         _lib = L

@@ -104,6 +104,10 @@ struct vitx_ctx {
     size_t weight_bytes = 0;             // device bytes held by weight matrices (vitx_ctx_weight_bytes)
     // LayerNorm fused into the residual GEMMs (GemmLn, kernels.h): norm2 rides in proj, the next layer's norm1 in fc2, wherever those GEMMs
     // run on the wide persistent kernel.  vitx_ctx_options::no_ln_fusion turns it off (every LayerNorm its own launch; same bits).
+    // F16 = the parity mode: q, k, v stay f32-grade into the attention products, as the reference's do (vit.cpp:826-858).  The QKV GEMM then
+    // emits two fp16 planes (EPI_BIAS_HILO) and the precise streaming kernel multiplies hi.hi + (hi.lo + lo.hi) / 2048 (attention_stream.hip).
+    // Head dim 64 only (the generic head-dim kernel keeps fp16 q, k, v).
+    bool prec_attn = false;
     bool ln_fuse = true;
     unsigned ln_epoch = 0;               // tag of the next fused launch (unique per launch; 0 is never used)
     unsigned ln_timeout = 20000;         // 200 us of the 100 MHz wall clock before a workgroup leaves its tile to the fix-up
@@ -119,7 +123,8 @@ struct vitx_ctx {
         unsigned long long *ln_sync = nullptr;   // [Mpad / 256][D / 256][256][2] statistics granules of the fused LayerNorm
         unsigned *ln_todo = nullptr;             // [ln_blocks] row blocks left to the fix-up launch; [ln_blocks] = the fallback counter
         int ln_blocks = 0;                       // Mpad / 256 of the slice's capacity
-        void *QKV = nullptr;         // [Mpad][3D]
+        void *QKV = nullptr;         // [Mpad][3D]; the parity mode's lo plane follows at qkv_lo_off elements
+        long qkv_lo_off = 0;
         void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
         void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
         void *Wq[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};   // just-in-time expansion of the current layer's quantised matrices
@@ -275,9 +280,9 @@ struct ProfScope {
 // row blocks that GEMM left behind, they are fixed by a launch of their own first.
 int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
          int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr, const GemmLn *ln = nullptr,
-         const GemmLn *fix = nullptr) {
+         const GemmLn *fix = nullptr, long hilo_off = 0) {
     GemmArgs a{};
-    a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos;
+    a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos; a.hilo_off = hilo_off;
     a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
     a.ln = ln;
     if (fix) {
@@ -289,6 +294,7 @@ int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const
     }
     double bytes = (double)M_real * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_real * N * out_elem_bytes;
     if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
+    if (epi == EPI_BIAS_HILO) bytes += (double)M_real * N * out_elem_bytes;        // the second plane
     if (ln) bytes += (double)M_real * N * 2;
     ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
     if (fused) {
@@ -340,6 +346,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->tune = tuning_for_device(device);
     if (!c->tune) { set_error("vitx_ctx_create: kernel bring-up on device %d failed: %s", device, hipGetErrorString(hipGetLastError())); return VITX_ERR_HIP; }
     c->split_first = opt.split_first;
+    c->prec_attn = dtype == VITX_F16 && c->D == c->H * 64 && !opt.f16_fast_attention;
     c->quant_on_device = !opt.quant_on_host;
     c->q4_fused_rows = opt.q4_fused_rows;
     c->graphs_on = opt.graph != 0;
@@ -423,7 +430,8 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
             if ((rc = c->dmalloc((void **)&sl.ln_todo, (Mpad / 256 + 1) * sizeof(unsigned), true))) return rc;
             sl.ln_blocks = (int)(Mpad / 256);
         }
-        if ((rc = c->dmalloc(&sl.QKV, Mpad * 3 * D * 2, true))) return rc;
+        if ((rc = c->dmalloc(&sl.QKV, Mpad * 3 * D * 2 * (c->prec_attn ? 2 : 1), true))) return rc;
+        sl.qkv_lo_off = c->prec_attn ? (long)(Mpad * 3 * D) : 0;
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
         if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
@@ -576,11 +584,14 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
         // qkv projection (vit.cpp:820-821); `fix_u`: row blocks of U the previous layer's fc2 left to the fix-up are normalised in its prologue
-        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
-                       fix_u.todo ? &fix_u : nullptr))) return rc;
+        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, c->prec_attn ? EPI_BIAS_HILO : EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
+                       fix_u.todo ? &fix_u : nullptr, sl.qkv_lo_off))) return rc;
         {   // attention (vit.cpp:826-866)
-            ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * (D / c->H), (double)M_real * 4 * D * eb);
-            if (!(skip & 1)) HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
+            ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * (D / c->H), (double)M_real * (c->prec_attn ? 7 : 4) * D * eb);
+            if (!(skip & 1)) {
+                if (c->prec_attn) HIP_TRY(launch_attention_stream(dt, true, sl.QKV, sl.U, n, N, D, c->H, sl.qkv_lo_off, st));
+                else HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
+            }
         }
         // output projection + residual (vit.cpp:868-873), then norm2 (vit.cpp:881-885) -> U2
         if ((rc = resid_gemm_ln(PC_GEMM_PROJ, sl.U, Wl[W_PROJ], w.proj_b, D, Fl[W_PROJ], w.ln2_w, w.ln2_b, sl.U2, &fix_u2))) return rc;
@@ -871,7 +882,7 @@ int vitx_op_layernorm(int dtype, const void *x, const void *w, const void *b, vo
     return VITX_OK;
 }
 static int op_gemm_impl(int dtype, int epi, int kernel, const void *a, const void *w, const void *bias, void *out, const void *pos, int M, int M_real, int N, int n_pad, int K, int tpi, void *stream) {
-    if (!a || !w || !out || !bias || epi < 0 || epi > EPI_PATCH || M_real <= 0 || M_real > M || (epi == EPI_PATCH && (!pos || tpi <= 0))) { set_error("vitx_op_gemm_ex: invalid argument"); return VITX_ERR_ARG; }
+    if (!a || !w || !out || !bias || epi < 0 || epi > EPI_BIAS_HILO || M_real <= 0 || M_real > M || (epi == EPI_PATCH && (!pos || tpi <= 0))) { set_error("vitx_op_gemm_ex: invalid argument"); return VITX_ERR_ARG; }
     if (M % 128 || N % 4 || K % 64) { set_error("vitx_op_gemm: M %% 128, N %% 4, K %% 64 must be 0"); return VITX_ERR_ARG; }
     const Tuning *t0 = tuning_for_device(-1);
     if (!t0) { set_error("vitx_op_gemm: kernel bring-up failed"); return VITX_ERR_HIP; }
@@ -883,6 +894,7 @@ static int op_gemm_impl(int dtype, int epi, int kernel, const void *a, const voi
     GemmArgs g{};
     g.A = a; g.W = w; g.bias = (const float *)bias; g.out = out; g.pos = (const float *)pos;
     g.M = M; g.M_real = M_real; g.N = N; g.N_pad = n_pad; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = tpi;
+    g.hilo_off = epi == EPI_BIAS_HILO ? (long)M * N : 0;          // the lo plane follows the [M][N] hi plane
     hipError_t e = launch_gemm(t, dtype, epi, g, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) { set_error("vitx_op_gemm: kernel %d cannot tile M %d N %d K %d", kernel, M, N, K); return VITX_ERR_UNSUPPORTED; }
     if (e != hipSuccess) { set_error("vitx_op_gemm: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
@@ -976,6 +988,8 @@ int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int 
         if (N <= 192 || N > 224) { set_error("vitx_op_attention: the persistent kernel takes 193..224 tokens, not %d", N); return VITX_ERR_UNSUPPORTED; }
     } else if (kernel == ATTN_SINGLE) {                      // single-pass kernel, also where the automatic choice prefers the pipelined one
         if (!attention_single_pass_supports(N)) { set_error("vitx_op_attention: no single-pass instantiation for %d tokens", N); return VITX_ERR_UNSUPPORTED; }
+    } else if (kernel == ATTN_STREAM) {                      // streaming two-pass kernel (attention_stream.hip), head dim 64
+        if (!attention_stream_supports(n_img, N, D, H)) { set_error("vitx_op_attention: the streaming kernel needs head_dim 64"); return VITX_ERR_UNSUPPORTED; }
     } else if (kernel != ATTN_AUTO && kernel != ATTN_FLOW) { set_error("vitx_op_attention: unknown kernel id %d", kernel); return VITX_ERR_ARG; }
     t.attn_kernel = kernel;
     hipError_t e = launch_attention(t, dtype, qkv, out, n_img, N, D, H, (hipStream_t)stream);
@@ -983,6 +997,23 @@ int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int 
     return VITX_OK;
 }
 int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) { return vitx_op_attention_ex(dtype, 0, qkv, out, n_img, N, D, H, stream); }
+// The parity mode's attention on f32 q, k, v (what the reference multiplies, vit.cpp:848,858): splits the rows into the two fp16 planes the
+// QKV GEMM's EPI_BIAS_HILO epilogue emits, then runs the precise streaming kernel.  Synchronous (allocates its own scratch).
+int vitx_op_attention_f32(const float *qkv_f32, void *out, int n_img, int N, int D, int H, void *stream) {
+    if (!qkv_f32 || !out || n_img <= 0 || N <= 0) return VITX_ERR_ARG;
+    if (!tuning_for_device(-1)) { set_error("vitx_op_attention_f32: kernel bring-up failed"); return VITX_ERR_HIP; }
+    if (!attention_stream_supports(n_img, N, D, H)) { set_error("vitx_op_attention_f32: head_dim must be 64"); return VITX_ERR_UNSUPPORTED; }
+    const size_t n = (size_t)n_img * N * 3 * D;
+    void *planes = nullptr;
+    HIP_TRY(hipMalloc(&planes, n * 2 * 2 + 64));
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_split_hilo(DT_F16, qkv_f32, planes, (char *)planes + n * 2, n, st);
+    if (e == hipSuccess) e = launch_attention_stream(DT_F16, true, planes, out, n_img, N, D, H, (long)n, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(planes);
+    if (e != hipSuccess) { set_error("vitx_op_attention_f32: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
 int vitx_op_softmax_dt(int dtype, const void *logits, void *probs, int rows, int cols, int ld, void *stream) {
     if (!logits || !probs || rows <= 0 || cols <= 0 || (dtype != VITX_F16 && dtype != VITX_BF16)) return VITX_ERR_ARG;
     hipError_t e = launch_softmax(dtype, (const float *)logits, (float *)probs, rows, cols, ld, (hipStream_t)stream);

@@ -16,6 +16,11 @@
 
 namespace vitx {
 
+// EPI_BIAS_HILO: lo = round((v - hi) * 2048) for two adjacent outputs, hi = the already rounded pair
+template <typename T> __device__ __forceinline__ typename Pair<T>::v2 hilo_lo_pair(float v0, float v1, typename Pair<T>::v2 hi) {
+    return round_pair<T>((v0 - (float)hi[0]) * kHiLoScale, (v1 - (float)hi[1]) * kHiLoScale);
+}
+
 // acc[t][u]: tile rows row0 + 16 t (row0 already includes l15), columns col0 + 16 u .. + 3 (col0 already includes 4 g4).
 // FULL: the whole workgroup tile is inside [0, M_real) x [0, N) -- no bounds checks, vector bias loads.  Otherwise every element is
 // checked on its own (N need not be a multiple of 4: the classifier head has as many columns as the model has classes).
@@ -35,7 +40,7 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][T
             }
         }
         const bool vec = FULL || (c + 3 < g.N && (g.ldo & 3) == 0);       // this lane's four columns exist and are 8 / 16-byte aligned
-        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_HILO) {
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 const int row = row0 + t * 16;
@@ -50,6 +55,16 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][T
                     const T s[4] = {p0[0], p0[1], p1[0], p1[1]};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (c + e < g.N) o[e] = s[e];
+                }
+                if constexpr (EPI == EPI_BIAS_HILO) {        // the lo plane: what the 16-bit rounding above dropped, scaled into the type's normal range
+                    const v2 l0 = hilo_lo_pair<T>(v[0], v[1], p0), l1 = hilo_lo_pair<T>(v[2], v[3], p1);
+                    T *ol = o + g.hilo_off;
+                    if (vec) *(v4 *)ol = v4{l0[0], l0[1], l1[0], l1[1]};
+                    else {
+                        const T s[4] = {l0[0], l0[1], l1[0], l1[1]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (c + e < g.N) ol[e] = s[e];
+                    }
                 }
             }
         } else {
@@ -129,7 +144,7 @@ __device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro
 // voff = this lane's byte offset in row layout (row lane >> 3 of the wave's block, 16-byte piece lane & 7), soff = tile origin,
 // soff8 = 8 rows, all in bytes of the output type; ro = buffer resource of the output matrix.
 template <typename T, int EPI, int NB, int AUX = 0>
-__device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const f32x4 (&bq)[4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane) {
+__device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const f32x4 (&bq)[4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane, int hilo_soff = 0) {
     // The 4 KiB patch is used as TWO halves of 16 rows x 128 B (r03): block b + 1 is converted and written into the other half between the
     // issue of block b's read-back and its stores, so the LDS write -> read round trip and the stores' issue time hide under the next
     // block's VALU work instead of serialising once per block.  (The LDS executes a wave's operations in issue order; the compiler-level
@@ -138,16 +153,21 @@ __device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const
     const int rd_off = (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16);         // row layout: row (lane>>3) + 8t, 16-byte piece lane&7
     const int wr_row = l15 * 128, x16 = (l15 & 7) * 16;                                    // MFMA layout: this lane's row of a 16-row block
     pp_lds_fence();
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_HILO) {
         typedef typename Pair<T>::v2 v2;
-        auto convert_write = [&](int b) {            // 16-row block b = accumulator tile b of the wave
-            char *pb = patch + (b & 1) * 2048 + wr_row;
+        // EPI_BIAS_HILO stores every 16-row block twice: pass q = 2 b + plane, plane 0 = hi at the tile's place, plane 1 = lo behind
+        // `hilo_soff` bytes (2 x the stores: 32 per NB = 4 tile, what pp_epi_stores counts)
+        constexpr int PL = EPI == EPI_BIAS_HILO ? 2 : 1;
+        auto convert_write = [&](int q) {            // 16-row block q / PL = accumulator tile of the wave, into half q & 1 of the patch
+            const int b = q / PL, plane = q % PL;
+            char *pb = patch + (q & 1) * 2048 + wr_row;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const f32x4 v = acc[b][u] + bq[u];
                 v2 p0, p1;
                 if constexpr (EPI == EPI_BIAS_GELU) { p0 = gelu_out_pair<T>(v[0], v[1]); p1 = gelu_out_pair<T>(v[2], v[3]); }
                 else { p0 = round_pair<T>(v[0], v[1]); p1 = round_pair<T>(v[2], v[3]); }
+                if (PL == 2 && plane == 1) { p0 = hilo_lo_pair<T>(v[0], v[1], p0); p1 = hilo_lo_pair<T>(v[2], v[3], p1); }
                 // columns u * 16 + 4 g4 .. + 3 -> bytes u * 32 + 8 g4 of the 128-byte patch row: 16-byte slot 2u + (g4 >> 1), half g4 & 1
                 *(u32x2 *)(pb + (((2 * u + (g4 >> 1)) * 16) ^ x16) + (g4 & 1) * 8) = u32x2{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
             }
@@ -155,14 +175,15 @@ __device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const
         };
         convert_write(0);
 #pragma unroll
-        for (int b = 0; b < 2 * NB; ++b) {
+        for (int q = 0; q < 2 * NB * PL; ++q) {
+            const int b = q / PL, plane = q % PL;
             u32x4 d[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) d[t] = *(const u32x4 *)(patch + (b & 1) * 2048 + t * 1024 + rd_off);
+            for (int t = 0; t < 2; ++t) d[t] = *(const u32x4 *)(patch + (q & 1) * 2048 + t * 1024 + rd_off);
             pp_lds_fence();
-            if (b + 1 < 2 * NB) convert_write(b + 1);
+            if (q + 1 < 2 * NB * PL) convert_write(q + 1);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) pp_store_b128<AUX>(d[t], ro, voff, soff + (b * 2 + t) * soff8);
+            for (int t = 0; t < 2; ++t) pp_store_b128<AUX>(d[t], ro, voff, soff + (b * 2 + t) * soff8 + (plane ? hilo_soff : 0));
         }
     } else {       // f32 outputs: one 16 x 32 block (2 KiB) per pass, pass c = (16-row block c >> 1, 32-column half c & 1)
         u32x4 res[2][2];                            // residual rows of the current and the next pass (loads run one pass ahead)
@@ -206,14 +227,14 @@ template <typename T, int EPI, int NB>
 __device__ __forceinline__ void epilogue16_tile(const GemmArgs &g, f32x4 (&acc)[2 * NB][4], bool full, int m0, int n0, int wave_row0, int wave_col0, char *patch, int lane) {
     const int l15 = lane & 15, g4 = lane >> 4;
     if constexpr (EPI != EPI_PATCH) {
-        constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
-        if (full && (size_t)g.M * g.ldo * esz < 0xf0000000u && (g.ldo & 3) == 0) {
+        constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_HILO) ? 2 : 4;
+        if (full && (size_t)g.M * g.ldo * esz + (EPI == EPI_BIAS_HILO ? (size_t)g.hilo_off * esz : 0) < 0xf0000000u && (g.ldo & 3) == 0) {
             f32x4 bq[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) bq[u] = g.bias ? *(const f32x4 *)(g.bias + n0 + wave_col0 + u * 16 + g4 * 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)0xffffffffu, 0x00020000);
             const int voff = ((wave_row0 + (lane >> 3)) * g.ldo + wave_col0) * esz + (lane & 7) * 16;
-            epilogue16_staged<T, EPI, NB>(acc, bq, ro, patch, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
+            epilogue16_staged<T, EPI, NB>(acc, bq, ro, patch, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane, (int)(g.hilo_off * esz));
             return;
         }
     }

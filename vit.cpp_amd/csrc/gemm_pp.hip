@@ -64,7 +64,7 @@ template <int N> __device__ __forceinline__ void pp_wait_vm_lgkm() { asm volatil
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 // whole-row stores of the staged epilogue per wave and tile (epilogue16_staged): the next tile's K loop skips over exactly this many
-template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }
+template <int EPI> __host__ __device__ constexpr int pp_epi_stores() { return (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 16 : 32; }      // (EPI_BIAS_HILO: two 16-bit planes = 32)
 
 // ---- EPI_BIAS_RESID + LayerNorm of the finished rows (GemmLn, kernels.h), for one full 256 x 256 tile of the persistent kernel.
 // Statistics follow device_common.h "LayerNorm statistics by 256-column tiles": this workgroup's tile is tile c = n0 / 256 of its rows;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
 #pragma unroll
             for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc16[t][0]), "v"(acc16[t][1]), "v"(acc16[t][2]), "v"(acc16[t][3]));
         } else if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
-            constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? 2 : 4;
+            constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_HILO) ? 2 : 4;
             // row layout of the stores: lane -> row (lane>>3) + 8t of a 32-row block, 16-byte piece lane&7 of the wave's 128-byte row segment
             const int voff = ((wr * 128 + (lane >> 3)) * g.ldo + wc * 64) * esz + (lane & 7) * 16;
             f32x4 bq[4];                       // bias of columns u * 16 + 4 g4 .. + 3, staged into the wave's patch by LDS-DMA during the K loop
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             // buffer op in a waterfall loop over the (uniform) SGPR offset
             if constexpr (LNF) relaxed = pp_epilogue_ln<T>(g, ln, acc16, rsrcO, smem, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, tid, m0, n0, ntn);
             else {
-                epilogue16_staged<T, EPI, 4>(acc16, bq, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane);
+                epilogue16_staged<T, EPI, 4>(acc16, bq, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane, (int)(g.hilo_off * esz));
                 relaxed = true;
             }
         } else {
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
 bool gemm_pp_supports(const GemmArgs &a) {
     // byte offsets into A, W and out are 32-bit (buffer addressing)
     const size_t lim = 0xf0000000u;
-    if ((size_t)a.M * a.lda * 2 > lim || (size_t)a.N_pad * a.ldw * 2 > lim || (size_t)(a.M + a.M / 64 + 2) * a.ldo * 4 > lim) return false;
+    if ((size_t)a.M * a.lda * 2 > lim || (size_t)a.N_pad * a.ldw * 2 > lim || (size_t)(a.M + a.M / 64 + 2) * a.ldo * 4 + (size_t)(a.hilo_off > 0 ? a.hilo_off : 0) * 2 > lim) return false;
     return a.M % pp::BM == 0 && a.N_pad % pp::BN == 0 && a.K % (2 * pp::BK) == 0 && a.K >= 2 * pp::BK && a.N % 4 == 0 && a.ldo % 4 == 0;
 }
 
@@ -618,6 +618,7 @@ static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t 
     case EPI_BIAS_RESID: return launch_pp_inst<T, EPI_BIAS_RESID, 0>(a, n_cu, stream, prepare);
     case EPI_BIAS_F32: return launch_pp_inst<T, EPI_BIAS_F32, 0>(a, n_cu, stream, prepare);
     case EPI_PATCH: return launch_pp_inst<T, EPI_PATCH, 0>(a, n_cu, stream, prepare);
+    case EPI_BIAS_HILO: return launch_pp_inst<T, EPI_BIAS_HILO, 0>(a, n_cu, stream, prepare);
     default: return hipErrorInvalidValue;
     }
 }

@@ -404,6 +404,7 @@ static hipError_t launch_ring_t(const GemmArgs &a, int epi, int cfg, int n_cu, h
     case EPI_BIAS_RESID: return launch_ring_e<T, EPI_BIAS_RESID, false>(a, cfg, n_cu, stream, prepare);
     case EPI_BIAS_F32: return launch_ring_e<T, EPI_BIAS_F32, false>(a, cfg, n_cu, stream, prepare);
     case EPI_PATCH: return launch_ring_e<T, EPI_PATCH, false>(a, cfg, n_cu, stream, prepare);
+    case EPI_BIAS_HILO: return launch_ring_e<T, EPI_BIAS_HILO, false>(a, cfg, n_cu, stream, prepare);
     default: return hipErrorInvalidValue;
     }
 }

@@ -14,8 +14,12 @@ enum {
     EPI_BIAS_GELU = 1,   // out(dtype)[m][n] = gelu_tanh(round(acc + bias[n]))     fc1      (vit.cpp:889-893)
     EPI_BIAS_RESID = 2,  // out(f32)[m][n]   = (acc + bias[n]) + out[m][n]         proj/fc2 (vit.cpp:868-873, 896-900)
     EPI_BIAS_F32 = 3,    // out(f32)[m][n]   = acc + bias[n]                       head     (vit.cpp:927-928)
-    EPI_PATCH = 4        // out(f32)[m + m/tpi + 1][n] = (acc + bias[n]) + pos[(m%tpi + 1)][n]   (vit.cpp:772-797)
+    EPI_PATCH = 4,       // out(f32)[m + m/tpi + 1][n] = (acc + bias[n]) + pos[(m%tpi + 1)][n]   (vit.cpp:772-797)
+    EPI_BIAS_HILO = 5    // qkv of the F16 parity mode: v = acc + bias[n] kept to f32 grade as TWO 16-bit planes, out[m][n] = hi = round(v) and
+                         // out[hilo_off + ..] = lo = round((v - hi) * 2048): the reference's q, k, v stay f32 into the attention products
+                         // (vit.cpp:826-858: ggml_mul_mat of f32 views), and hi + lo / 2048 reproduces v to 2^-22
 };
+constexpr float kHiLoScale = 2048.0f, kHiLoInv = 1.0f / 2048.0f;
 
 struct GemmArgs {
     const void *A; const void *W; const float *bias; void *out; const float *pos;
@@ -26,6 +30,7 @@ struct GemmArgs {
     int K;        // multiple of 64
     int lda, ldw, ldo;
     int tpi;      // EPI_PATCH: patch tokens per image (g*g)
+    long hilo_off;  // EPI_BIAS_HILO: ELEMENT offset of the lo plane behind `out` (a whole number of rows; the byte offset must fit 32 bits)
     int dbg;      // ablation bits of the ring kernel's laboratory build (VITX_LAB only; 0 in the product)
     // q4_0 weights kept in block form (launch_gemm_q4 only): W = nibble plane [N_pad][K/2] bytes (16 per block), Wscale = f16 block
     // scales [N_pad][K/32]; both planes are the file's block_q4_0 fields re-laid out, 4.5 bits per weight
@@ -78,7 +83,7 @@ bool gemm_q4_supports(const GemmArgs &a);
 // (or host threads) of one process never share launch state.  The product library reads NO environment variable here: the family
 // overrides below are explicit parameters of vitx_op_gemm_ex / vitx_op_attention_ex (parity tests); only the laboratory build
 // (-DVITX_LAB, tools/) maps VITX_* variables onto them.
-enum { ATTN_AUTO = 0, ATTN_SINGLE = 1, ATTN_FLOW = 3, ATTN_PERSIST = 4 };
+enum { ATTN_AUTO = 0, ATTN_SINGLE = 1, ATTN_FLOW = 3, ATTN_PERSIST = 4, ATTN_STREAM = 5 };
 struct Tuning {
     int device = 0;
     int n_cu = 256;          // compute units of THIS device
@@ -122,6 +127,13 @@ void patch_embed_permute_k(const uint16_t *w, uint16_t *w_perm, int N, int Cin, 
 hipError_t launch_layernorm(int dtype, const float *x, long ldx, const float *w, const float *b, void *y, long ldy, int M, int D, float eps, hipStream_t stream, int group = 1, long gstride = 0);
 // fused per-(image,head) attention  (vit.cpp:826-866)
 hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream);
+// Streaming two-pass kernel (attention_stream.hip), head dim 64, any token count.  precise = false: the long-sequence kernel of both
+// operand types; precise = true (f16 only): the F16 parity mode's f32-grade products -- qkv is then the HI plane of the QKV GEMM's
+// EPI_BIAS_HILO output and the LO plane lies lo_off elements behind it.  n_img == 0: device bring-up (dynamic-LDS attribute).
+hipError_t launch_attention_stream(int dtype, bool precise, const void *qkv, void *out, int n_img, int N, int D, int H, long lo_off, hipStream_t stream);
+bool attention_stream_supports(int n_img, int N, int D, int H);
+// x[n] f32 -> hi[n] = round(x), lo[n] = round((x - hi) * 2048) in the operand type (what EPI_BIAS_HILO emits; parity-test entry point)
+hipError_t launch_split_hilo(int dtype, const float *x, void *hi, void *lo, size_t n, hipStream_t stream);
 bool attention_supports(int N, int D, int H);     // any token count; head_dim 64 (tuned kernels) or any other multiple of 8 up to 128 (generic kernel)
 bool attention_single_pass_supports(int N);       // instantiation table of the register-resident kernel
 bool layernorm_supports(int D);

@@ -162,6 +162,7 @@ static hipError_t launch_gemm_t(int epi, const GemmArgs &a, hipStream_t stream, 
         VITX_GEMM_CASE(EPI_BIAS_RESID)
         VITX_GEMM_CASE(EPI_BIAS_F32)
         VITX_GEMM_CASE(EPI_PATCH)
+        VITX_GEMM_CASE(EPI_BIAS_HILO)
     default: return hipErrorInvalidValue;
     }
 #undef VITX_GEMM_CASE
@@ -230,7 +231,7 @@ hipError_t launch_gemm(const Tuning &t, int dtype, int epi, const GemmArgs &a, h
             const int rows_main = m_main * 256;
             GemmArgs head = a, tail = a;
             head.M = rows_main; head.M_real = std::min(a.M_real, rows_main);
-            const size_t esz_out = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? 2 : 4;
+            const size_t esz_out = (epi == EPI_BIAS || epi == EPI_BIAS_GELU || epi == EPI_BIAS_HILO) ? 2 : 4;
             tail.A = (const char *)a.A + (size_t)rows_main * a.lda * 2;
             tail.out = (char *)a.out + (size_t)rows_main * a.ldo * esz_out;
             tail.M = a.M - rows_main; tail.M_real = a.M_real - rows_main;
@@ -1256,6 +1257,7 @@ hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *o
     if ((t.attn_kernel == ATTN_PERSIST || t.attn_kernel == ATTN_AUTO) && attention_persist_supports(n_img, N, D))
         return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags);
     if (t.attn_kernel == ATTN_PERSIST) return hipErrorInvalidValue;
+    if (t.attn_kernel == ATTN_STREAM) return launch_attention_stream(dtype, false, qkv, out, n_img, N, D, H, 0, stream);
     const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_kernel == ATTN_SINGLE);
     if (t.attn_kernel == ATTN_FLOW || !single)
         return dtype == DT_F16 ? launch_attention_flow<_Float16>(qkv, out, n_img, N, D, H, stream, t.attn_flags) : launch_attention_flow<__bf16>(qkv, out, n_img, N, D, H, stream, t.attn_flags);
@@ -1269,13 +1271,15 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
     GemmArgs none{};
     hipError_t e;
     for (int dt = 0; dt < 2; ++dt) {
-        for (int epi = 0; epi <= EPI_PATCH; ++epi) {
+        for (int epi = 0; epi <= EPI_BIAS_HILO; ++epi) {
             for (int cfg : {945, 445, 245, 122}) if ((e = launch_gemm_ring(t, dt, epi, none, cfg, nullptr, true)) != hipSuccess) return e;
             if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16, true>(epi, none, nullptr, true) : launch_gemm_t<__bf16, true>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
         if (dt == 0 && (e = launch_patch_embed(0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, true)) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_flow<_Float16>(nullptr, nullptr, 0, 64, 64, 1, nullptr) : launch_attention_flow<__bf16>(nullptr, nullptr, 0, 64, 64, 1, nullptr))) != hipSuccess) return e;
+        if ((e = launch_attention_stream(dt, false, nullptr, nullptr, 0, 64, 64, 1, 0, nullptr)) != hipSuccess) return e;
+        if (dt == DT_F16 && (e = launch_attention_stream(dt, true, nullptr, nullptr, 0, 64, 64, 1, 0, nullptr)) != hipSuccess) return e;
         if ((e = (dt == DT_F16 ? launch_attention_persist<_Float16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr) : launch_attention_persist<__bf16>(nullptr, nullptr, 0, 224, 64, 1, t.n_cu, nullptr))) != hipSuccess) return e;
         for (int nkt : kAttnNkt) {
             e = dt == DT_F16 ? launch_attention_t<_Float16>(nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr) : launch_attention_t<__bf16>(nullptr, nullptr, 0, nkt * 32, 64, 1, nullptr);
