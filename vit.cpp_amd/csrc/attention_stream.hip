@@ -25,16 +25,37 @@
 namespace vitx {
 
 namespace as {
+#ifndef AS_W
+#define AS_W 8          // waves per workgroup of the fast build
+#endif
+#ifndef AS_OCC
+#define AS_OCC 4        // waves per SIMD the fast build is compiled for (the pipelined step, AS_PIPE, needs 194 VGPRs: AS_OCC 2)
+#endif
+#ifndef AS_NSLOT
+#define AS_NSLOT 3      // ring slots of the fast build
+#endif
+#ifndef AS_FLAGS
+#define AS_FLAGS 0      // ablation builds (tools/scratch only; garbage results): 1 no exp arithmetic, 2 no V reads / PV products, 4 no K reads, 8 no QK^T products, 16 no DMA / barriers after the prologue, 32 no pass 1
+#endif
+constexpr int FL = AS_FLAGS;
+#ifndef AS_PIPE
+#define AS_PIPE 0       // fast build: 1 = software-pipelined steps (PV of step s - 1 beside the exp arithmetic of step s), 0 = the plain per-step schedule
+#endif
 constexpr int CK = 64;               // keys per chunk
 constexpr int KB = CK * 128;         // bytes of one 64-row plane image (K or V rows of 64 dims x 2 B)
-constexpr int NSLOT = 3;
+template <bool PREC> constexpr int nslot() { return PREC ? 3 : AS_NSLOT; }
+template <bool PREC> constexpr int nwaves() { return PREC ? 8 : AS_W; }
 template <bool PREC> constexpr int slot_bytes() { return (PREC ? 4 : 2) * KB; }      // [K hi | K lo | V hi | V lo] or [K | V]
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vm_rt(int n) {       // n = DMA instructions of the youngest stage: 0, 1, 2 or 4
-    if (n == 0) wait_vm<0>(); else if (n == 1) wait_vm<1>(); else if (n == 2) wait_vm<2>(); else wait_vm<4>();
+__device__ __forceinline__ void wait_vm_rt(int n) {       // n = DMA instructions allowed to stay in flight (wave-uniform)
+    switch (n) {
+    case 0: wait_vm<0>(); break; case 1: wait_vm<1>(); break; case 2: wait_vm<2>(); break; case 3: wait_vm<3>(); break; case 4: wait_vm<4>(); break;
+    case 6: wait_vm<6>(); break; case 8: wait_vm<8>(); break; case 12: wait_vm<12>(); break; case 16: wait_vm<16>(); break;
+    default: wait_vm<0>(); break;
+    }
 }
 typedef int i4 __attribute__((ext_vector_type(4)));
 typedef short s4 __attribute__((ext_vector_type(4)));
@@ -52,11 +73,15 @@ template <int CNT> __device__ __forceinline__ void wait_lgkm8(s4 &a, s4 &b, s4 &
 }
 }  // namespace as
 
-template <typename T, int QT, bool PREC>
-__global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, int qblocks, int n_img, long lo_off) {
+template <typename T, int QT, bool PREC, int W, int NSLOT, int RES>
+__global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, int qblocks, int n_img, long lo_off) {
     using namespace as;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PL = PREC ? 2 : 1, SLOT = slot_bytes<PREC>();
+    // RES > 0 (precise build, 193..224 tokens): the RES 16-key score tiles of a query stay in registers between the K stream and the V stream --
+    // K is streamed and multiplied ONCE (5 instead of 8 products per key and query); a ring slot then holds one operand's two planes
+    static_assert(RES == 0 || (PREC && QT == 1), "resident scores: precise build only");
+    constexpr int PL = PREC ? 2 : 1, SLOT = RES ? 2 * KB : slot_bytes<PREC>(), VBASE = RES ? 0 : PL * KB, NT = W * 64, OPS = 512 / NT, AHEAD = NSLOT - 1;
+    static_assert(512 % NT == 0 && NSLOT >= 2, "a plane image is 512 pieces of 16 bytes");
     typedef typename Elem<T>::v8 v8;
     typedef typename Pair<T>::v2 v2;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
@@ -79,26 +104,39 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
     const unsigned remaining = (unsigned)min((size_t)0xf0000000u, ((size_t)(n_img - b) * N * 3 * D - h * 64) * 2);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)remaining, 0x00020000);
     __amdgpu_buffer_rsrc_t rsrc_lo = __builtin_amdgcn_make_buffer_rsrc((void *)(base + (PREC ? lo_off : 0)), 0, (int)remaining, 0x00020000);
-    int koff, voff;
-    {
-        int rr, sl; swz_inv(tid, rr, sl);                                          // K: swizzled row image (swz_byte), permutation on the source side
-        koff = rr * row_bytes + D * 2 + sl * 16;
-        const int vr = tid >> 3, vs = (tid & 7) ^ (((vr >> 1) & 3) << 1);          // V: row-major, 32-byte chunks XOR-ed with (row >> 1) & 3
-        voff = vr * row_bytes + 2 * D * 2 + vs * 16;
+    int koff[2], voff[2];           // (fixed bound, OPS <= 2: hipcc 7.2 silently drops the host-side instantiation of a kernel whose lambda captures an array sized by a constexpr LOCAL that depends on a template parameter)
+    static_assert(OPS <= 2, "at least 4 waves");
+#pragma unroll
+    for (int r = 0; r < OPS; ++r) {
+        const int piece = r * NT + tid;
+        int rr, sl; swz_inv(piece, rr, sl);                                        // K: swizzled row image (swz_byte), permutation on the source side
+        koff[r] = rr * row_bytes + D * 2 + sl * 16;
+        const int vr = piece >> 3, vs = (piece & 7) ^ (((vr >> 1) & 3) << 1);      // V: row-major, 32-byte chunks XOR-ed with (row >> 1) & 3
+        voff[r] = vr * row_bytes + 2 * D * 2 + vs * 16;
     }
     auto stage = [&](int i) {            // stage i: pass-1 chunk i (K only) for i < nch, pass-2 chunk i - nch (K and V) after that
         const bool with_v = i >= nch;
         const int c = with_v ? i - nch : i;
         char *dst = smem + (i % NSLOT) * SLOT + wave * 1024;
         const int so = c * CK * row_bytes;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst), 16, koff, so, 0, 0);
-        if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + KB), 16, koff, so, 0, 0);
+        if (!(RES && with_v)) {
+#pragma unroll
+            for (int r = 0; r < OPS; ++r) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst + r * NT * 16), 16, koff[r], so, 0, 0);
+                if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + r * NT * 16 + KB), 16, koff[r], so, 0, 0);
+            }
+        }
         if (with_v) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst + PL * KB), 16, voff, so, 0, 0);
-            if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + PL * KB + KB), 16, voff, so, 0, 0);
+#pragma unroll
+            for (int r = 0; r < OPS; ++r) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst + r * NT * 16 + VBASE), 16, voff[r], so, 0, 0);
+                if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + r * NT * 16 + VBASE + KB), 16, voff[r], so, 0, 0);
+            }
         }
     };
-    auto stage_ops = [&](int i) { return i >= nstage ? 0 : (i >= nch ? 2 * PL : PL); };
+    auto stage_ops = [&](int i) { return i >= nstage ? 0 : ((i >= nch && !RES) ? 2 * PL * OPS : PL * OPS); };
+    // DMA instructions of stages i + 2 .. i + AHEAD: what may stay in flight when stage i + 1 must have landed
+    auto ops_after = [&](int i) { int n = 0; for (int a = 2; a <= AHEAD; ++a) n += stage_ops(i + a); return n; };
 
     // ---- Q fragments (B operand of S^T = K . Q^T): lane (l15 = query of the tile, g4) holds dims k2 * 32 + g4 * 8 .. + 7
     v8 qh[QT][2], ql[QT][2];
@@ -111,8 +149,8 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
             ql[qt][k2] = PREC ? *(const v8 *)(base + lo_off + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8) : qh[qt][k2];
         }
     }
-    stage(0);
-    if (nstage > 1) stage(1);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) if (a < nstage) stage(a);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
@@ -131,13 +169,18 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
     {
         const int r = 4 * g4 + (l15 >> 2), x = (r >> 1) & 3;       // this lane's V row within a 16-key group and its chunk swizzle
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vrd[dt] = PL * KB + r * 128 + ((dt ^ x) << 5) + (l15 & 3) * 8;
+        for (int dt = 0; dt < 4; ++dt) vrd[dt] = VBASE + r * 128 + ((dt ^ x) << 5) + (l15 & 3) * 8;
     }
 
     // K fragments of one 32-key step: [16-key tile j][k2] (+ the lo plane)
     i4 kf[2][2], kl[2][2];
     auto read_k = [&](unsigned sb, auto ks_) {
         constexpr int ks = decltype(ks_)::value;
+        if constexpr ((FL & 4) != 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) { kf[0][k2] = i4{(int)sb, ks, k2, 1}; kf[1][k2] = i4{ks, (int)sb, 2, k2}; }
+            return;
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             ds_read_b128<ks * 4096>(kf[0][k2], sb + krd[0][k2]); ds_read_b128<ks * 4096>(kf[1][k2], sb + krd[1][k2]);
@@ -146,6 +189,7 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
     };
     auto wait_k = [&](auto cnt_) {       // the K reads have landed; cnt = LDS reads issued after them
         constexpr int cnt = decltype(cnt_)::value;
+        if constexpr ((FL & 4) != 0) return;
         if constexpr (PREC) wait_lgkm8<cnt>(kf[0][0], kf[0][1], kf[1][0], kf[1][1], kl[0][0], kl[0][1], kl[1][0], kl[1][1]);
         else wait_lgkm4<cnt>(kf[0][0], kf[0][1], kf[1][0], kf[1][1]);
     };
@@ -153,6 +197,7 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
     auto score = [&](int j, int qt) -> f32x4 {
         const v8 k0 = __builtin_bit_cast(v8, kf[j][0]), k1 = __builtin_bit_cast(v8, kf[j][1]);
         f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr ((FL & 8) != 0) return f32x4{(float)k0[0], (float)k1[1], (float)k0[2] + (float)qh[qt][0][0], (float)k1[3]};
         a = Elem<T>::mfma16(k0, qh[qt][0], a);
         a = Elem<T>::mfma16(k1, qh[qt][1], a);
         if constexpr (PREC) {
@@ -192,19 +237,105 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
             }
     };
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 8> I8;
     typedef std::true_type TT; typedef std::false_type FF;
+    constexpr bool PIPE = !PREC && AS_PIPE != 0;
+    // fast build: the 8 products of a 32-key step (2 key tiles x QT query tiles x 2 k-steps) in k-step-major order -- four (2 QT) independent
+    // accumulator chains, so the second product of a chain is issued four products (64 cycles) after the first instead of right behind it
+    auto qk8 = [&](f32x4 (&sc)[2][QT]) {
+        v8 k[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) k[j][k2] = __builtin_bit_cast(v8, kf[j][k2]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                if constexpr ((FL & 8) != 0) sc[j][qt] = f32x4{(float)k[j][0][0], (float)k[j][1][1], (float)k[j][0][2] + (float)qh[qt][0][0], (float)k[j][1][3]};
+                else sc[j][qt] = Elem<T>::mfma16(k[j][0], qh[qt][0], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            }
+        if constexpr ((FL & 8) == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) sc[j][qt] = Elem<T>::mfma16(k[j][1], qh[qt][1], sc[j][qt]);
+        }
+    };
+    auto p1_pipe = [&](unsigned sb, int key0, auto masked_, bool two) {      // one chunk of pass 1: the K fragments of step 1 are requested behind the products of step 0
+        constexpr bool MASK = decltype(masked_)::value;
+        f32x4 sc[2][QT];
+        read_k(sb, I0{}); wait_k(I0{});
+        qk8(sc);
+        if (two) read_k(sb, I1{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                if (MASK) mask(sc[j][qt], key0 + j * 16);
+                mx[qt] = fmaxf(fmaxf(mx[qt], sc[j][qt][0]), sc[j][qt][1]); mx[qt] = fmaxf(fmaxf(mx[qt], sc[j][qt][2]), sc[j][qt][3]);
+            }
+        if (two) {
+            wait_k(I0{});
+            qk8(sc);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    if (MASK) mask(sc[j][qt], key0 + 32 + j * 16);
+                    mx[qt] = fmaxf(fmaxf(mx[qt], sc[j][qt][0]), sc[j][qt][1]); mx[qt] = fmaxf(fmaxf(mx[qt], sc[j][qt][2]), sc[j][qt][3]);
+                }
+        }
+    };
+    f32x4 sres[RES > 0 ? RES : 1];
+    if constexpr (RES > 0) {
+        constexpr int NCH = (RES * 16 + CK - 1) / CK;              // chunks that hold a real key (the launcher guarantees nch == NCH)
+        static_for<0, NCH>([&](auto c_) {
+            constexpr int c = decltype(c_)::value;
+            if (c + AHEAD < nstage) stage(c + AHEAD);
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) {
+                const unsigned sb = lds0 + (unsigned)((c % NSLOT) * SLOT);
+                static_for<0, 2>([&](auto ks_) {
+                    constexpr int ks = decltype(ks_)::value;
+                    if constexpr (4 * c + 2 * ks < RES) {
+                        read_k(sb, ks_); wait_k(I0{});
+                        static_for<0, 2>([&](auto j_) {
+                            constexpr int j = decltype(j_)::value, t = 4 * c + 2 * ks + j;
+                            if constexpr (t < RES) {
+                                f32x4 sc = score(j, 0);
+                                if constexpr (t >= 12) mask(sc, t * 16);            // only the tiles past key 191 can hold padded keys (N > 192)
+                                sres[t] = sc;
+                                mx[0] = fmaxf(fmaxf(mx[0], sc[0]), sc[1]); mx[0] = fmaxf(fmaxf(mx[0], sc[2]), sc[3]);
+                            }
+                        });
+                    }
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm_rt(ops_after(c));
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
     for (int c = 0; c < nch; ++c) {
         const int i = c;
-        if (i + 2 < nstage) stage(i + 2);
+        if ((FL & 32) != 0 || RES > 0) break;
+        if (i + AHEAD < nstage && !(FL & 16)) stage(i + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
             const unsigned sb = lds0 + (unsigned)((i % NSLOT) * SLOT);
             const int key0 = c * CK;
-            if (c + 1 < nch) { p1_step(sb, key0, I0{}, FF{}); p1_step(sb, key0, I1{}, FF{}); }
-            else { p1_step(sb, key0, I0{}, TT{}); if (key0 + 32 < N) p1_step(sb, key0, I1{}, TT{}); }
+            if constexpr (PIPE) {
+                if (c + 1 < nch) p1_pipe(sb, key0, FF{}, true); else p1_pipe(sb, key0, TT{}, key0 + 32 < N);
+            } else {
+                if (c + 1 < nch) { p1_step(sb, key0, I0{}, FF{}); p1_step(sb, key0, I1{}, FF{}); }
+                else { p1_step(sb, key0, I0{}, TT{}); if (key0 + 32 < N) p1_step(sb, key0, I1{}, TT{}); }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        wait_vm_rt(stage_ops(i + 2));                   // stage i + 1 has landed; the pieces of stage i + 2 may stay in flight
+        if (FL & 16) continue;
+        wait_vm_rt(ops_after(i));                       // stage i + 1 has landed; the pieces of the stages after it may stay in flight
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -225,6 +356,7 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
     // V^T fragments of 16-dim tiles DT0 .. DT0 + NDT - 1 of one 32-key step (hi plane, and lo for PREC)
     auto read_v = [&](unsigned sb, auto ks_, auto dt0_, auto ndt_) {
         constexpr int ks = decltype(ks_)::value, DT0 = decltype(dt0_)::value, NDT = decltype(ndt_)::value;
+        if constexpr ((FL & 2) != 0) return;
         static_for<DT0, DT0 + NDT>([&](auto dt_) {
             constexpr int dt = decltype(dt_)::value;
             ds_read_tr<ks * 4096>(vf[dt][0], sb + vrd[dt]); ds_read_tr<ks * 4096 + 2048>(vf[dt][1], sb + vrd[dt]);
@@ -233,6 +365,11 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
     };
     auto pv = [&](const v8 (&p)[QT], auto dt0_, auto ndt_) {
         constexpr int DT0 = decltype(dt0_)::value, NDT = decltype(ndt_)::value;
+        if constexpr ((FL & 2) != 0) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) o[qt][DT0][0] += (float)p[qt][0] + (float)p[qt][5];
+            return;
+        }
         static_for<DT0, DT0 + NDT>([&](auto dt_) {
             constexpr int dt = decltype(dt_)::value;
             const s8 both = __builtin_shufflevector(vf[dt][0], vf[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
@@ -245,12 +382,11 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
             }
         });
     };
-    typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 8> I8;
     auto p2_step = [&](unsigned sb, int key0, auto ks_, auto masked_) {
         constexpr bool MASK = decltype(masked_)::value;
         constexpr int ks = decltype(ks_)::value;
         read_k(sb, ks_);
-        if constexpr (!PREC) { read_v(sb, ks_, I0{}, I4{}); wait_k(I8{}); }          // 4 + 8 LDS reads in flight (the counter holds 15)
+        if constexpr (!PREC) { read_v(sb, ks_, I0{}, I4{}); if constexpr ((FL & 2) != 0) wait_k(I0{}); else wait_k(I8{}); }          // 4 + 8 LDS reads in flight (the counter holds 15)
         else wait_k(I0{});
         // numerators per AttnExp<T>, one 16-key tile at a time (its four scores per query die as soon as they are exponentiated); row sum of the
         // ROUNDED values (they are what the PV product sees); k-slot j of lane group g4 = key 4 g4 + j of the first, 16 + 4 g4 + (j - 4) of
@@ -262,7 +398,8 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
             for (int qt = 0; qt < QT; ++qt) {
                 f32x4 sc = score(j, qt);
                 if (MASK) mask(sc, key0 + ks * 32 + j * 16);
-                e[qt][2 * j] = AttnExp<T>::pair(sc[0], sc[1], nmx[qt]); e[qt][2 * j + 1] = AttnExp<T>::pair(sc[2], sc[3], nmx[qt]);
+                if constexpr ((FL & 1) != 0) { e[qt][2 * j] = round_pair<T>(sc[0] + nmx[qt], sc[1]); e[qt][2 * j + 1] = round_pair<T>(sc[2], sc[3]); }
+                else { e[qt][2 * j] = AttnExp<T>::pair(sc[0], sc[1], nmx[qt]); e[qt][2 * j + 1] = AttnExp<T>::pair(sc[2], sc[3], nmx[qt]); }
                 sum[qt] = Pair<T>::sum2(e[qt][2 * j + 1], Pair<T>::sum2(e[qt][2 * j], sum[qt]));
             }
             if (PREC && j == 0) read_v(sb, ks_, I0{}, I2{});                           // 8 reads: dims 0..31, both planes (the K fragments of tile 1 are in registers already)
@@ -271,7 +408,7 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) p[qt] = v8{e[qt][0][0], e[qt][0][1], e[qt][1][0], e[qt][1][1], e[qt][2][0], e[qt][2][1], e[qt][3][0], e[qt][3][1]};
         if constexpr (!PREC) {
-            wait_lgkm8<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1], vf[2][0], vf[2][1], vf[3][0], vf[3][1]);
+            if constexpr ((FL & 2) == 0) wait_lgkm8<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1], vf[2][0], vf[2][1], vf[3][0], vf[3][1]);
             pv(p, I0{}, I4{});
         } else {
             wait_lgkm8<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1], vl[0][0], vl[0][1], vl[1][0], vl[1][1]);
@@ -281,24 +418,113 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
             pv(p, I2{}, I2{});
         }
     };
+    // fast build, software-pipelined (r04: the plain per-step schedule ran every phase at its full serial cost -- the waves of a SIMD go through
+    // reads -> QK^T -> exp -> PV in lock step, one barrier per chunk re-aligns them -- profiles/r04/attention_577_ablation.txt): the PV products
+    // of step s - 1 (operands: last step's probabilities and its V^T fragments, both in registers) are issued BESIDE the exp arithmetic of
+    // step s, so matrix pipe and VALU of the same wave run together; the K fragments of the chunk's second step are requested right behind the
+    // products of its first, the V^T fragments of step s behind the PV products that free their registers.
+    v8 p_prev[QT];
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) p_prev[qt] = __builtin_bit_cast(v8, i4{0, 0, 0, 0});
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { vf[dt][0] = s4{0, 0, 0, 0}; vf[dt][1] = s4{0, 0, 0, 0}; }       // zero probabilities x zero V: the first PV adds nothing
+    }
+    auto v_landed = [&]() { if constexpr ((FL & 2) == 0) wait_lgkm8<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1], vf[2][0], vf[2][1], vf[3][0], vf[3][1]); };
+    auto p2_pipe = [&](unsigned sb, int key0, auto ks_, auto masked_, bool more) {
+        constexpr bool MASK = decltype(masked_)::value;
+        constexpr int ks = decltype(ks_)::value;
+        if constexpr (ks == 0) { read_k(sb, I0{}); wait_k(I0{}); }
+        else { if constexpr ((FL & 2) != 0) wait_k(I0{}); else wait_k(I8{}); }       // K of step 1 was requested BEFORE the 8 V^T reads of step 0
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 sc[2][QT];
+        qk8(sc);
+        if constexpr (ks == 0) { if (more) read_k(sb, I1{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks == 1) v_landed();                                           // V^T of step 0 (younger than the K reads waited for above)
+        pv(p_prev, I0{}, I4{});                                                      // step s - 1: 8 products ...
+        v2 e[QT][4];                                                                 // ... beside this step's numerators
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                if (MASK) mask(sc[j][qt], key0 + ks * 32 + j * 16);
+                if constexpr ((FL & 1) != 0) { e[qt][2 * j] = round_pair<T>(sc[j][qt][0] + nmx[qt], sc[j][qt][1]); e[qt][2 * j + 1] = round_pair<T>(sc[j][qt][2], sc[j][qt][3]); }
+                else { e[qt][2 * j] = AttnExp<T>::pair(sc[j][qt][0], sc[j][qt][1], nmx[qt]); e[qt][2 * j + 1] = AttnExp<T>::pair(sc[j][qt][2], sc[j][qt][3], nmx[qt]); }
+                sum[qt] = Pair<T>::sum2(e[qt][2 * j + 1], Pair<T>::sum2(e[qt][2 * j], sum[qt]));
+            }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {            // one product, two transcendentals, four other VALU instructions, eight times
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x400, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(sb, ks_, I0{}, I4{});                                                 // this step's V^T fragments, into the registers the products above have read
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) p_prev[qt] = v8{e[qt][0][0], e[qt][0][1], e[qt][1][0], e[qt][1][1], e[qt][2][0], e[qt][2][1], e[qt][3][0], e[qt][3][1]};
+    };
+    if constexpr (RES > 0) {
+        constexpr int NCH = (RES * 16 + CK - 1) / CK, NKS = (RES + 1) / 2;
+        static_for<0, NCH>([&](auto c_) {
+            constexpr int c = decltype(c_)::value, i = NCH + c;
+            if (i + AHEAD < nstage) stage(i + AHEAD);
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) {
+                const unsigned sb = lds0 + (unsigned)((i % NSLOT) * SLOT);
+                static_for<0, 2>([&](auto ks_) {
+                    constexpr int ks = decltype(ks_)::value, t2 = 2 * c + ks;
+                    if constexpr (t2 < NKS) {
+                        read_v(sb, ks_, I0{}, I2{});                                   // dims 0..31, both planes: in flight under the exp arithmetic
+                        const v2 e0 = AttnExp<T>::pair(sres[2 * t2][0], sres[2 * t2][1], nmx[0]), e1 = AttnExp<T>::pair(sres[2 * t2][2], sres[2 * t2][3], nmx[0]);
+                        v2 e2 = __builtin_bit_cast(v2, 0u), e3 = __builtin_bit_cast(v2, 0u);            // an odd last tile: probabilities 0 (its V rows are finite)
+                        sum[0] = Pair<T>::sum2(e1, Pair<T>::sum2(e0, sum[0]));
+                        if constexpr (2 * t2 + 1 < RES) {
+                            e2 = AttnExp<T>::pair(sres[2 * t2 + 1][0], sres[2 * t2 + 1][1], nmx[0]); e3 = AttnExp<T>::pair(sres[2 * t2 + 1][2], sres[2 * t2 + 1][3], nmx[0]);
+                            sum[0] = Pair<T>::sum2(e3, Pair<T>::sum2(e2, sum[0]));
+                        }
+                        v8 p[QT];
+                        p[0] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
+                        wait_lgkm8<0>(vf[0][0], vf[0][1], vf[1][0], vf[1][1], vl[0][0], vl[0][1], vl[1][0], vl[1][1]);
+                        pv(p, I0{}, I2{});
+                        read_v(sb, ks_, I2{}, I2{});
+                        wait_lgkm8<0>(vf[2][0], vf[2][1], vf[3][0], vf[3][1], vl[2][0], vl[2][1], vl[3][0], vl[3][1]);
+                        pv(p, I2{}, I2{});
+                    }
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (c + 1 < NCH) {
+                wait_vm_rt(ops_after(i));
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    }
     for (int c = 0; c < nch; ++c) {
         const int i = nch + c;
-        if (i + 2 < nstage) stage(i + 2);
+        if (RES > 0) break;
+        if (i + AHEAD < nstage && !(FL & 16)) stage(i + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
             const unsigned sb = lds0 + (unsigned)((i % NSLOT) * SLOT);
             const int key0 = c * CK;
-            if (c + 1 < nch) { p2_step(sb, key0, I0{}, FF{}); p2_step(sb, key0, I1{}, FF{}); }
-            else { p2_step(sb, key0, I0{}, TT{}); if (key0 + 32 < N) p2_step(sb, key0, I1{}, TT{}); }
+            if constexpr (PIPE) {
+                if (c + 1 < nch) { p2_pipe(sb, key0, I0{}, FF{}, true); p2_pipe(sb, key0, I1{}, FF{}, false); }
+                else { const bool two = key0 + 32 < N; p2_pipe(sb, key0, I0{}, TT{}, two); if (two) p2_pipe(sb, key0, I1{}, TT{}, false); }
+                v_landed();               // before the barrier: the slot is re-staged right behind it, and the next chunk's first PV takes these fragments
+            } else {
+                if (c + 1 < nch) { p2_step(sb, key0, I0{}, FF{}); p2_step(sb, key0, I1{}, FF{}); }
+                else { p2_step(sb, key0, I0{}, TT{}); if (key0 + 32 < N) p2_step(sb, key0, I1{}, TT{}); }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nch) {
-            wait_vm_rt(stage_ops(i + 2));
+        if (c + 1 < nch && !(FL & 16)) {
+            wait_vm_rt(ops_after(i));
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (!active) return;
+    if constexpr (PIPE) pv(p_prev, I0{}, I4{});           // the last step's products
     // ---- O / sum, rounded once; lane (l15 = query, g4) holds O[query][dt * 16 + 4 g4 .. + 3].  v_permlane16_swap: the even lane row gives
     // its odd tile and takes the odd row's even tile -> 8 consecutive dims per lane, two 16-byte stores covering whole 64-byte lines
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -325,13 +551,13 @@ __global__ __launch_bounds__(512, PREC ? 2 : 4) void attention_stream_kernel(con
     }
 }
 
-template <typename T, int QT, bool PREC>
+template <typename T, int QT, bool PREC, int RES>
 static hipError_t launch_stream_inst(const void *qkv, void *out, int n_img, int N, int D, int H, long lo_off, hipStream_t stream) {
-    constexpr int lds = as::NSLOT * as::slot_bytes<PREC>();
-    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_stream_kernel<T, QT, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      // device bring-up
-    const int tasks = (N + 16 * QT - 1) / (16 * QT), qblocks = (tasks + 7) / 8, items = n_img * H;
+    constexpr int W = as::nwaves<PREC>(), NSLOT = as::nslot<PREC>(), lds = NSLOT * (RES ? 2 * as::KB : as::slot_bytes<PREC>());
+    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_stream_kernel<T, QT, PREC, W, NSLOT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      // device bring-up
+    const int tasks = (N + 16 * QT - 1) / (16 * QT), qblocks = (tasks + W - 1) / W, items = n_img * H;
     const unsigned grid = (unsigned)(((items + 7) / 8) * 8 * qblocks);
-    hipLaunchKernelGGL((attention_stream_kernel<T, QT, PREC>), dim3(grid), dim3(512), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, qblocks, n_img, lo_off);
+    hipLaunchKernelGGL((attention_stream_kernel<T, QT, PREC, W, NSLOT, RES>), dim3(grid), dim3(W * 64), lds, stream, (const T *)qkv, (T *)out, N, D, H, items, qblocks, n_img, lo_off);
     return hipGetLastError();
 }
 
@@ -340,8 +566,21 @@ bool attention_stream_supports(int n_img, int N, int D, int H) { return N > 0 &&
 // precise = the F16 parity mode's f32-grade products: qkv holds the hi plane, the lo plane lies lo_off ELEMENTS behind it (EPI_BIAS_HILO)
 hipError_t launch_attention_stream(int dtype, bool precise, const void *qkv, void *out, int n_img, int N, int D, int H, long lo_off, hipStream_t stream) {
     if (n_img != 0 && !attention_stream_supports(n_img, N, D, H)) return hipErrorInvalidValue;
-    if (precise) return dtype == DT_F16 ? launch_stream_inst<_Float16, 1, true>(qkv, out, n_img, N, D, H, lo_off, stream) : hipErrorInvalidValue;
-    return dtype == DT_F16 ? launch_stream_inst<_Float16, 2, false>(qkv, out, n_img, N, D, H, 0, stream) : launch_stream_inst<__bf16, 2, false>(qkv, out, n_img, N, D, H, 0, stream);
+    if (precise) {
+        if (dtype != DT_F16) return hipErrorInvalidValue;
+        if (n_img == 0) {       // bring-up: every precise build
+            hipError_t e = launch_stream_inst<_Float16, 1, true, 0>(qkv, out, 0, N, D, H, lo_off, stream);
+            if (e == hipSuccess) e = launch_stream_inst<_Float16, 1, true, 13>(qkv, out, 0, N, D, H, lo_off, stream);
+            if (e == hipSuccess) e = launch_stream_inst<_Float16, 1, true, 14>(qkv, out, 0, N, D, H, lo_off, stream);
+            return e;
+        }
+        // 193..224 tokens (ViT-*/16 at 224^2): the score tiles stay in registers, K is streamed once.  One build per token count, at every
+        // batch size: an image's result does not depend on the batch it arrives in.
+        if (N > 192 && N <= 208) return launch_stream_inst<_Float16, 1, true, 13>(qkv, out, n_img, N, D, H, lo_off, stream);
+        if (N > 208 && N <= 224) return launch_stream_inst<_Float16, 1, true, 14>(qkv, out, n_img, N, D, H, lo_off, stream);
+        return launch_stream_inst<_Float16, 1, true, 0>(qkv, out, n_img, N, D, H, lo_off, stream);
+    }
+    return dtype == DT_F16 ? launch_stream_inst<_Float16, 2, false, 0>(qkv, out, n_img, N, D, H, 0, stream) : launch_stream_inst<__bf16, 2, false, 0>(qkv, out, n_img, N, D, H, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
