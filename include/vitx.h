@@ -286,6 +286,9 @@ int vitx_op_attention_ex(int dtype, int kernel, const void *d_qkv, void *d_out, 
  * split into hi / lo fp16 planes (what the QKV GEMM's epi 5 emits) and every product is hi.hi + (hi.lo + lo.hi) / 2048.  d_out [n_img * N][D]
  * fp16.  Head dim 64.  Synchronous. */
 int vitx_op_attention_f32(const float *d_qkv_f32, void *d_out, int n_img, int N, int D, int H, void *stream);
+/* The same kernel on planes that are already split (the output of vitx_op_gemm_ex epi 5): d_hi [n_img * N][3 D] fp16, the lo plane lo_off
+ * ELEMENTS behind it.  Only enqueues on `stream`. */
+int vitx_op_attention_planes(const void *d_hi, long lo_off, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* probs = softmax(logits) over num_classes with the reference's fp16 exp rounding (vit.cpp:931). */
 int vitx_op_softmax(const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);
 /* The same with the rounding type of the exp explicit (VITX_F16 = the reference's LUT semantics, VITX_BF16 = the bf16 engine). */

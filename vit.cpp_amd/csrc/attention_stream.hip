@@ -26,7 +26,7 @@ namespace vitx {
 
 namespace as {
 #ifndef AS_W
-#define AS_W 8          // waves per workgroup of the fast build
+#define AS_W 16         // waves per workgroup of the fast and the resident-score builds
 #endif
 #ifndef AS_OCC
 #define AS_OCC 4        // waves per SIMD the fast build is compiled for (the pipelined step, AS_PIPE, needs 194 VGPRs: AS_OCC 2)
@@ -43,8 +43,20 @@ constexpr int FL = AS_FLAGS;
 #endif
 constexpr int CK = 64;               // keys per chunk
 constexpr int KB = CK * 128;         // bytes of one 64-row plane image (K or V rows of 64 dims x 2 B)
-template <bool PREC> constexpr int nslot() { return PREC ? 3 : AS_NSLOT; }
-template <bool PREC> constexpr int nwaves() { return PREC ? 8 : AS_W; }
+#ifndef AS_PNSLOT
+#define AS_PNSLOT 3
+#endif
+#ifndef AS_AUX
+#define AS_AUX 0          // cache-policy bits of the K / V DMA and the Q loads (lab: 17 = sc0 sc1)
+#endif
+#ifndef AS_CLAIM
+#define AS_CLAIM 1
+#endif
+#ifndef AS_PARANOID
+#define AS_PARANOID 0
+#endif
+template <bool PREC> constexpr int nslot() { return PREC ? AS_PNSLOT : AS_NSLOT; }
+template <bool PREC, int RES> constexpr int nwaves() { return (PREC && RES == 0) ? 8 : AS_W; }       // the two-pass precise build needs 150 registers: 8 waves
 template <bool PREC> constexpr int slot_bytes() { return (PREC ? 4 : 2) * KB; }      // [K hi | K lo | V hi | V lo] or [K | V]
 template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
@@ -74,16 +86,26 @@ template <int CNT> __device__ __forceinline__ void wait_lgkm8(s4 &a, s4 &b, s4 &
 }  // namespace as
 
 template <typename T, int QT, bool PREC, int W, int NSLOT, int RES>
-__global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, int qblocks, int n_img, long lo_off) {
+__global__ __launch_bounds__(W * 64, W == 16 ? 4 : 2) void attention_stream_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int items, int qblocks, int n_img, long lo_off) {
     using namespace as;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // RES > 0 (precise build, 193..224 tokens): the RES 16-key score tiles of a query stay in registers between the K stream and the V stream --
     // K is streamed and multiplied ONCE (5 instead of 8 products per key and query); a ring slot then holds one operand's two planes
     static_assert(RES == 0 || (PREC && QT == 1), "resident scores: precise build only");
-    constexpr int PL = PREC ? 2 : 1, SLOT = RES ? 2 * KB : slot_bytes<PREC>(), VBASE = RES ? 0 : PL * KB, NT = W * 64, OPS = 512 / NT, AHEAD = NSLOT - 1;
-    static_assert(512 % NT == 0 && NSLOT >= 2, "a plane image is 512 pieces of 16 bytes");
+    // a plane image is 512 pieces of 16 bytes: moved by the first DT = min(NT, 512) threads, OPS pieces each (waves past them only compute)
+    constexpr int PL = PREC ? 2 : 1, SLOT = RES ? 2 * KB : slot_bytes<PREC>(), VBASE = RES ? 0 : PL * KB, NT = W * 64, DT = NT < 512 ? NT : 512, OPS = 512 / DT, AHEAD = NSLOT - 1;
+    static_assert(512 % DT == 0 && NSLOT >= 2, "a plane image is 512 pieces of 16 bytes");
     typedef typename Elem<T>::v8 v8;
     typedef typename Pair<T>::v2 v2;
+#if AS_CLAIM
+    // Claim the whole register file of every SIMD the workgroup occupies, as the GEMM and the persistent attention kernels do by their size:
+    // 8 waves x 256 registers, or 16 waves x 128.  r04: with registers to spare, waves of ANOTHER kernel (the other sub-batch stream's
+    // LayerNorm) were placed on the same SIMDs and their cross-lane sums came out wrong in ~1 % of the rows (profiles/r04/coresidency_layernorm.txt)
+    // -- an interaction between this kernel's instruction stream and a co-resident wave's DPP / permute traffic that nothing in the ISA
+    // documents and that the kernels which fill their CUs never showed.  A full register file admits no foreign wave.
+    if constexpr (W == 8) asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    else { static_assert(W == 16, "8 waves x 256 or 16 waves x 128 registers"); asm volatile("v_mov_b32 v127, 0" ::: "v127"); }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // blockIdx -> (item, query block): blocks equal mod 8 run on one XCD; an item's query blocks are consecutive there (its K / V stay in that L2)
@@ -108,13 +130,15 @@ __global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_ke
     static_assert(OPS <= 2, "at least 4 waves");
 #pragma unroll
     for (int r = 0; r < OPS; ++r) {
-        const int piece = r * NT + tid;
+        const int piece = r * DT + (tid & (DT - 1));
         int rr, sl; swz_inv(piece, rr, sl);                                        // K: swizzled row image (swz_byte), permutation on the source side
         koff[r] = rr * row_bytes + D * 2 + sl * 16;
         const int vr = piece >> 3, vs = (piece & 7) ^ (((vr >> 1) & 3) << 1);      // V: row-major, 32-byte chunks XOR-ed with (row >> 1) & 3
         voff[r] = vr * row_bytes + 2 * D * 2 + vs * 16;
     }
+    const bool dma_wave = wave * 64 < DT;               // wave-uniform
     auto stage = [&](int i) {            // stage i: pass-1 chunk i (K only) for i < nch, pass-2 chunk i - nch (K and V) after that
+        if (!dma_wave) return;
         const bool with_v = i >= nch;
         const int c = with_v ? i - nch : i;
         char *dst = smem + (i % NSLOT) * SLOT + wave * 1024;
@@ -122,19 +146,19 @@ __global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_ke
         if (!(RES && with_v)) {
 #pragma unroll
             for (int r = 0; r < OPS; ++r) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst + r * NT * 16), 16, koff[r], so, 0, 0);
-                if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + r * NT * 16 + KB), 16, koff[r], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst + r * DT * 16), 16, koff[r], so, 0, AS_AUX);
+                if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + r * DT * 16 + KB), 16, koff[r], so, 0, AS_AUX);
             }
         }
         if (with_v) {
 #pragma unroll
             for (int r = 0; r < OPS; ++r) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst + r * NT * 16 + VBASE), 16, voff[r], so, 0, 0);
-                if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + r * NT * 16 + VBASE + KB), 16, voff[r], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(dst + r * DT * 16 + VBASE), 16, voff[r], so, 0, AS_AUX);
+                if (PREC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LPTR(dst + r * DT * 16 + VBASE + KB), 16, voff[r], so, 0, AS_AUX);
             }
         }
     };
-    auto stage_ops = [&](int i) { return i >= nstage ? 0 : ((i >= nch && !RES) ? 2 * PL * OPS : PL * OPS); };
+    auto stage_ops = [&](int i) { return (i >= nstage || !dma_wave) ? 0 : ((i >= nch && !RES) ? 2 * PL * OPS : PL * OPS); };
     // DMA instructions of stages i + 2 .. i + AHEAD: what may stay in flight when stage i + 1 must have landed
     auto ops_after = [&](int i) { int n = 0; for (int a = 2; a <= AHEAD; ++a) n += stage_ops(i + a); return n; };
 
@@ -145,8 +169,9 @@ __global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_ke
         const int qrow = min(q0 + qt * 16 + l15, N - 1);
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-            qh[qt][k2] = *(const v8 *)(base + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8);
-            ql[qt][k2] = PREC ? *(const v8 *)(base + lo_off + (size_t)qrow * 3 * D + k2 * 32 + g4 * 8) : qh[qt][k2];
+            const int qo = (qrow * 3 * D + k2 * 32 + g4 * 8) * 2;
+            qh[qt][k2] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, qo, 0, AS_AUX));
+            ql[qt][k2] = PREC ? __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, qo, 0, AS_AUX)) : qh[qt][k2];
         }
     }
 #pragma unroll
@@ -321,6 +346,7 @@ __global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_ke
     for (int c = 0; c < nch; ++c) {
         const int i = c;
         if ((FL & 32) != 0 || RES > 0) break;
+        if (AS_PARANOID) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         if (i + AHEAD < nstage && !(FL & 16)) stage(i + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
@@ -502,6 +528,7 @@ __global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_ke
     for (int c = 0; c < nch; ++c) {
         const int i = nch + c;
         if (RES > 0) break;
+        if (AS_PARANOID) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         if (i + AHEAD < nstage && !(FL & 16)) stage(i + AHEAD);
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
@@ -553,7 +580,7 @@ __global__ __launch_bounds__(W * 64, PREC ? 2 : AS_OCC) void attention_stream_ke
 
 template <typename T, int QT, bool PREC, int RES>
 static hipError_t launch_stream_inst(const void *qkv, void *out, int n_img, int N, int D, int H, long lo_off, hipStream_t stream) {
-    constexpr int W = as::nwaves<PREC>(), NSLOT = as::nslot<PREC>(), lds = NSLOT * (RES ? 2 * as::KB : as::slot_bytes<PREC>());
+    constexpr int W = as::nwaves<PREC, RES>(), NSLOT = as::nslot<PREC>(), lds = NSLOT * (RES ? 2 * as::KB : as::slot_bytes<PREC>());
     if (n_img == 0) return hipFuncSetAttribute((const void *)attention_stream_kernel<T, QT, PREC, W, NSLOT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);      // device bring-up
     const int tasks = (N + 16 * QT - 1) / (16 * QT), qblocks = (tasks + W - 1) / W, items = n_img * H;
     const unsigned grid = (unsigned)(((items + 7) / 8) * 8 * qblocks);

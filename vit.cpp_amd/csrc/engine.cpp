@@ -583,16 +583,54 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             ProfScope ps(c, st, PC_LAYERNORM, 0, (double)M_real * D * (4 + eb));
             if (!(skip & 2)) HIP_TRY(launch_layernorm(dt, sl.X, D, w.ln1_w, w.ln1_b, sl.U, D, M_real, D, c->hp.eps, st));
         }
+#ifdef VITX_LAB
+        if (il == 0 && getenv("VITX_SNAP")) {      // lab: X and the first norm1 output of this slice
+            static int run1[4] = {0, 0, 0, 0};
+            const int si = (int)(&sl - &c->slices[0]);
+            std::vector<char> hx((size_t)M_real * D * 4), hu((size_t)M_real * D * 2);
+            HIP_TRY(hipMemcpyAsync(hx.data(), sl.X, hx.size(), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hu.data(), sl.U, hu.size(), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            char fn[512];
+            snprintf(fn, sizeof fn, "%s/snap_s%d_r%d_x0.bin", getenv("VITX_SNAP"), si, run1[si]); { FILE *f = fopen(fn, "wb"); if (f) { fwrite(hx.data(), 1, hx.size(), f); fclose(f); } }
+            snprintf(fn, sizeof fn, "%s/snap_s%d_r%d_ln1.bin", getenv("VITX_SNAP"), si, run1[si]); { FILE *f = fopen(fn, "wb"); if (f) { fwrite(hu.data(), 1, hu.size(), f); fclose(f); } }
+            ++run1[si];
+        }
+#endif
         // qkv projection (vit.cpp:820-821); `fix_u`: row blocks of U the previous layer's fc2 left to the fix-up are normalised in its prologue
-        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, c->prec_attn ? EPI_BIAS_HILO : EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
+#ifdef VITX_LAB
+        static const int prec_dbg = getenv("VITX_PREC_DBG") ? atoi(getenv("VITX_PREC_DBG")) : 0;      // 1: HILO GEMM + fast attention on the hi plane; 2: plain GEMM + precise attention (lo plane stays zero)
+#else
+        constexpr int prec_dbg = 0;
+#endif
+        if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, (c->prec_attn && prec_dbg != 2) ? EPI_BIAS_HILO : EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
                        fix_u.todo ? &fix_u : nullptr, sl.qkv_lo_off))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * (D / c->H), (double)M_real * (c->prec_attn ? 7 : 4) * D * eb);
             if (!(skip & 1)) {
-                if (c->prec_attn) HIP_TRY(launch_attention_stream(dt, true, sl.QKV, sl.U, n, N, D, c->H, sl.qkv_lo_off, st));
+                if (c->prec_attn && prec_dbg != 1) {
+                    if (prec_dbg == 3) HIP_TRY(hipDeviceSynchronize());          // lab: the attention kernel runs alone on the device
+                    HIP_TRY(launch_attention_stream(dt, true, sl.QKV, sl.U, n, N, D, c->H, sl.qkv_lo_off, st));
+                    if (prec_dbg == 3) HIP_TRY(hipDeviceSynchronize());
+                    if (prec_dbg == 4) HIP_TRY(hipStreamSynchronize(st));        // lab: host-side order after it, other stream keeps running
+                }
                 else HIP_TRY(launch_attention(*c->tune, dt, sl.QKV, sl.U, n, N, D, c->H, st));
             }
         }
+#ifdef VITX_LAB
+        if (il == 0 && getenv("VITX_SNAP")) {      // lab: QKV (hi plane) and the attention output of layer 0 of this slice, to files (synchronous)
+            static int run[4] = {0, 0, 0, 0};
+            const int si = (int)(&sl - &c->slices[0]);
+            std::vector<char> hq((size_t)M_real * 3 * D * 2), hu((size_t)M_real * D * 2);
+            HIP_TRY(hipMemcpyAsync(hq.data(), sl.QKV, hq.size(), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hu.data(), sl.U, hu.size(), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            char fn[512];
+            snprintf(fn, sizeof fn, "%s/snap_s%d_r%d_qkv.bin", getenv("VITX_SNAP"), si, run[si]); { FILE *f = fopen(fn, "wb"); if (f) { fwrite(hq.data(), 1, hq.size(), f); fclose(f); } }
+            snprintf(fn, sizeof fn, "%s/snap_s%d_r%d_u.bin", getenv("VITX_SNAP"), si, run[si]); { FILE *f = fopen(fn, "wb"); if (f) { fwrite(hu.data(), 1, hu.size(), f); fclose(f); } }
+            ++run[si];
+        }
+#endif
         // output projection + residual (vit.cpp:868-873), then norm2 (vit.cpp:881-885) -> U2
         if ((rc = resid_gemm_ln(PC_GEMM_PROJ, sl.U, Wl[W_PROJ], w.proj_b, D, Fl[W_PROJ], w.ln2_w, w.ln2_b, sl.U2, &fix_u2))) return rc;
         // MLP (vit.cpp:889-900), then the NEXT layer's norm1 (vit.cpp:808-812) -> U; the last layer is followed by the cls-row norm instead
@@ -997,6 +1035,16 @@ int vitx_op_attention_ex(int dtype, int kernel, const void *qkv, void *out, int 
     return VITX_OK;
 }
 int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, int D, int H, void *stream) { return vitx_op_attention_ex(dtype, 0, qkv, out, n_img, N, D, H, stream); }
+// The precise kernel on planes that are already split (what the QKV GEMM's epilogue 5 emits): d_hi [n_img * N][3 D] fp16, the lo plane lo_off
+// ELEMENTS behind it.  Only enqueues on `stream`.
+int vitx_op_attention_planes(const void *d_hi, long lo_off, void *out, int n_img, int N, int D, int H, void *stream) {
+    if (!d_hi || !out || n_img <= 0 || N <= 0 || lo_off <= 0) return VITX_ERR_ARG;
+    if (!tuning_for_device(-1)) { set_error("vitx_op_attention_planes: kernel bring-up failed"); return VITX_ERR_HIP; }
+    if (!attention_stream_supports(n_img, N, D, H)) { set_error("vitx_op_attention_planes: head_dim must be 64"); return VITX_ERR_UNSUPPORTED; }
+    hipError_t e = launch_attention_stream(DT_F16, true, d_hi, out, n_img, N, D, H, lo_off, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_op_attention_planes: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
 // The parity mode's attention on f32 q, k, v (what the reference multiplies, vit.cpp:848,858): splits the rows into the two fp16 planes the
 // QKV GEMM's EPI_BIAS_HILO epilogue emits, then runs the precise streaming kernel.  Synchronous (allocates its own scratch).
 int vitx_op_attention_f32(const float *qkv_f32, void *out, int n_img, int N, int D, int H, void *stream) {
