@@ -137,11 +137,12 @@ typedef struct vitx_ctx_options {
     int32_t q4_fused_rows;    /* q4_0 GEMMs with at most this many rows expand the blocks inside the GEMM's LDS-fill path (default 0 = never) */
     int32_t split_first;      /* with 2 streams: images of the first sub-batch (default 0 = the tile-round model decides) */
     int32_t no_ln_fusion;     /* 1: every LayerNorm runs as its own kernel (default: norm2 / the next norm1 ride in the proj / fc2 GEMMs) */
-    int32_t ln_test;          /* parity tests only: 1 = every fifth tile of a LayerNorm-fusing GEMM behaves as if a peer had timed out, 3 = and withholds its
+    int32_t ln_test;          /* parity tests only, honoured only as VITX_LN_TEST_KEY | mode (anything else is refused): mode 1 = every fifth tile of a LayerNorm-fusing GEMM behaves as if a peer had timed out, 3 = and withholds its
                                  statistics (real 50 us time-outs): the consumer-side fix-up must then give the same bits */
     int32_t f16_fast_attention; /* VITX_F16 contexts: 1 = q, k, v rounded to fp16 for the attention products (the r03 behaviour: one QKV plane, the fast
                                  attention kernels) instead of the parity mode's f32-grade products (two fp16 planes, three MFMAs per product) */
 } vitx_ctx_options;
+#define VITX_LN_TEST_KEY 0x7e570000
 int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype, const vitx_ctx_options *options, vitx_ctx **out);
 void vitx_ctx_free(vitx_ctx *c);
 int vitx_ctx_max_batch(const vitx_ctx *c);
@@ -273,6 +274,10 @@ long long vitx_ctx_ln_fallbacks(vitx_ctx *c);
 /* Diagnostic: internal sub-batch streams the context re-created because a 40 us probe showed them serialised with the caller's stream
  * (the runtime's stream -> hardware-queue mapping depends on the other streams alive in the process).  0 in a fresh process. */
 int vitx_ctx_stream_retries(const vitx_ctx *c);
+/* 1 = norm2 / the next norm1 are computed in the proj / fc2 GEMMs' epilogues where the shape allows it (the default on an 8-XCD device); 0 = every
+ * LayerNorm is its own launch (option no_ln_fusion, graph cache, a device that does not report 8 XCDs); -1 = the context switched the fusion off
+ * itself because more than 8 tiles per forward (averaged over 16 forwards) had to fall back -- peers' CUs held by other work.  Same bits in all cases. */
+int vitx_ctx_ln_fusion_active(const vitx_ctx *c);
 /* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
 int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* kernel 0 = automatic, 1 = single-pass kernel (N <= 224, 257-288 or 577-608 tokens only),

@@ -211,7 +211,9 @@ def test_timm_state_dict_converter(pkg, binding, tmp_path):
     sd["norm_pre.weight"] = torch.ones(hp.hidden_size); sd["norm_pre.bias"] = torch.zeros(hp.hidden_size)
     pth = str(tmp_path / "m.pth"); torch.save(sd, pth)
     out = str(tmp_path / "timm.gguf"); want = str(tmp_path / "want.gguf")
-    assert pkg.convert.main(["--timm-state-dict", pth, out, "--ftype", "1"]) == 0
+    with pytest.raises(ValueError, match="--heads"):           # 128 is not a released timm width: the head count is not guessed (r03 advisor)
+        pkg.convert.main(["--timm-state-dict", pth, out, "--ftype", "1"])
+    assert pkg.convert.main(["--timm-state-dict", pth, out, "--ftype", "1", "--heads", "2"]) == 0
     pkg.ggml_file.write_model(want, hp, w, id2label=None, ftype=1)
     pm = binding.Model(out)
     h = pm.hparams
@@ -222,12 +224,17 @@ def test_timm_state_dict_converter(pkg, binding, tmp_path):
     vhp = pkg.synth.hparams_for(vname)
     vw = pkg.synth.make_weights(vhp, seed=6, head_scale=4.0, in_chans=1)
     torch.save({"module.vitstr." + k: torch.from_numpy(v.copy()) for k, v in vw.items()}, pth)
-    assert pkg.convert.main(["--timm-state-dict", pth, out]) == 0
+    assert pkg.convert.main(["--timm-state-dict", pth, out, "--heads", "2"]) == 0
     vm = binding.Model(out)
     assert vm.in_channels == 1 and vm.seq_len == 25 and vm.label(1) == "[s]"
     # unsupported timm variants are named, not silently mis-written
     bad = dict(sd); bad["blocks.0.ls1.gamma"] = torch.ones(hp.hidden_size)
     with pytest.raises(ValueError, match="ls1"):
-        pkg.convert.convert_timm_state_dict(bad, out)
+        pkg.convert.convert_timm_state_dict(bad, out, heads=2)
     with pytest.raises(ValueError, match="missing"):
-        pkg.convert.convert_timm_state_dict({k: v for k, v in sd.items() if k != "head.bias"}, out)
+        pkg.convert.convert_timm_state_dict({k: v for k, v in sd.items() if k != "head.bias"}, out, heads=2)
+    # ViT-H/14's width: 16 heads of 80, not 1280 / 64 = 20 heads (the shape synth's vit_mini_hd80 mimics)
+    hname = "vit_mini_hd80_patch14_112"
+    hhp = pkg.synth.hparams_for(hname)
+    hw = pkg.synth.make_weights(hhp, seed=7, head_scale=4.0)
+    assert pkg.convert.convert_timm_state_dict({k: torch.from_numpy(v.copy()) for k, v in hw.items()}, out).num_attention_heads == 16

@@ -283,15 +283,24 @@ def test_forward_base_bs256_bf16_vs_oracle(pkg, binding, oracle, torch_gpu):
     om = oracle.OracleModel(path)
     rl, rp = om.forward(imgs[CHECK_IDS], oracle.REF)
     bl, bp, xd = om.forward(imgs[CHECK_IDS], oracle.GPU_BF16, dump=True)
+    _, _, xref = om.forward(imgs[CHECK_IDS], oracle.REF, dump=True)
     got = probs[CHECK_IDS]
     print("bf16 ViT-B bs256: max|dp| vs REF %.3e, vs bf16-oracle %.3e; max|dlogit| vs REF %.3e" % (np.abs(got - rp).max(), np.abs(got - bp).max(), np.abs(logits[CHECK_IDS] - rl).max()))
     assert (got.argmax(1) == rp.argmax(1)).all()
     assert np.abs(got - rp).max() <= 2e-2
     assert np.abs(got - bp).max() <= 6e-3
-    xd = xd.reshape(x.shape)
+    xd = xd.reshape(x.shape); xref = xref.reshape(x.shape)
+    worst_own = worst_ref = 0.0
     for il in range(1, x.shape[0]):
         rms = float(np.sqrt((xd[il] ** 2).mean()))
-        assert float(np.sqrt(((x[il] - xd[il]) ** 2).mean())) / rms <= 1.5e-2, il
+        own = float(np.sqrt(((x[il] - xd[il]) ** 2).mean())) / rms
+        # and against the REFERENCE semantics (fp16 rounding points), which no edit to the bf16 oracle can move (r03 advisor: the same-mode oracle tracks the
+        # implementation; this bound is the independent one): bf16's 8-bit significand against fp16's 11 -- 2.5e-2 of the stream's RMS after every layer
+        ref = float(np.sqrt(((x[il] - xref[il]) ** 2).mean())) / float(np.sqrt((xref[il] ** 2).mean()))
+        worst_own, worst_ref = max(worst_own, own), max(worst_ref, ref)
+        assert own <= 1.5e-2, il
+        assert ref <= 2.5e-2, (il, ref)
+    print("bf16 ViT-B bs256 residual stream: worst relative RMS vs bf16-oracle %.3e, vs REF %.3e" % (worst_own, worst_ref))
 
 
 def test_forward_large384_full_depth_vs_oracle(pkg, binding, oracle, torch_gpu):

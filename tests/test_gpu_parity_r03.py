@@ -278,6 +278,19 @@ def test_group_vitstr_output_size(pkg, binding, torch_gpu):
     grp.close(); model.close()
 
 
+def test_ln_test_switch_needs_its_key_and_fusion_is_reported(pkg, binding, torch_gpu):
+    """The fault-injection switch is refused without VITX_LN_TEST_KEY (r03 advisor: it ships in the public options struct); a default context on
+    an MI355X reports fused LayerNorms, a no_ln_fusion context does not."""
+    path = pkg.synth.cached_synthetic("vit_base_patch16_224", head_scale=4.0)
+    model = binding.Model(path)
+    with pytest.raises(binding.VitxError):
+        binding.Context(model, max_batch=64, dtype=binding.BF16, ln_test=1)
+    a = binding.Context(model, max_batch=64, dtype=binding.BF16)
+    b = binding.Context(model, max_batch=64, dtype=binding.BF16, no_ln_fusion=1)
+    assert a.ln_fusion_active() == 1 and b.ln_fusion_active() == 0
+    a.close(); b.close(); model.close()
+
+
 @pytest.mark.parametrize("ln_test", [1, 3])
 @pytest.mark.parametrize("name,n", [("vit_base_patch16_224", 256), ("vit_large_patch16_384", 70)])
 def test_forward_ln_fallback_fixed_by_the_consumer_gemm(pkg, binding, torch_gpu, name, n, ln_test):
@@ -290,7 +303,7 @@ def test_forward_ln_fallback_fixed_by_the_consumer_gemm(pkg, binding, torch_gpu,
     g = torch.Generator(device="cuda").manual_seed(7 + n)
     imgs = torch.randn((n, hp.img_size, hp.img_size, 3), device="cuda", generator=g)
     outs = {}
-    for key, opts in (("plain", {"no_ln_fusion": 1}), ("forced", {"ln_test": ln_test})):
+    for key, opts in (("plain", {"no_ln_fusion": 1}), ("forced", {"ln_test": binding.LN_TEST_KEY | ln_test})):
         model = binding.Model(path)
         ctx = binding.Context(model, device=0, max_batch=n, dtype=binding.BF16, **opts)
         probs = torch.empty((n, hp.num_classes), device="cuda"); logits = torch.empty_like(probs)

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VITX_LIB") or os.path.join(_HERE, "libvitx.so")
 
 F16, BF16 = 0, 1
+LN_TEST_KEY = 0x7e570000        # vitx_ctx_options::ln_test is honoured only as LN_TEST_KEY | mode
 BICUBIC, BILINEAR = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_BIAS_F32, EPI_PATCH, EPI_BIAS_HILO = 0, 1, 2, 3, 4, 5
 GEMM_AUTO, GEMM_PP, GEMM_AUTO_SPLIT = 0, 1, 2          # vitx_op_gemm_ex `kernel` (or a ring configuration: 945, 445, 245, 122)
@@ -29,7 +30,7 @@ EXPORTS = [
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_ctx_shares_weights", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
-    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_op_attention_f32", "vitx_op_attention_planes", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
+    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_ctx_ln_fusion_active", "vitx_op_attention_f32", "vitx_op_attention_planes", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
 
 
@@ -121,6 +122,7 @@ def lib():
         L.vitx_probe_mfma.argtypes = [ip, ip, ip, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.vitx_model_in_channels.argtypes = [vp]; L.vitx_model_seq_len.argtypes = [vp]; L.vitx_ctx_out_rows.argtypes = [vp]
         L.vitx_ctx_split.argtypes = [vp, ip, C.POINTER(C.c_int32), ip]
+        L.vitx_ctx_ln_fusion_active.argtypes = [vp]
         L.vitx_op_attention_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp]
         L.vitx_op_attention_planes.argtypes = [vp, C.c_long, vp, ip, ip, ip, ip, vp]
         L.vitx_preprocess_vitstr_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, C.POINTER(C.c_float)]
@@ -327,6 +329,10 @@ class Context:
     def ln_fallbacks(self) -> int:
         """GEMM tiles whose fused LayerNorm was left to the fix-up launch since the context was created (vitx_ctx_ln_fallbacks)."""
         return int(lib().vitx_ctx_ln_fallbacks(self._h))
+
+    def ln_fusion_active(self) -> int:
+        """1 fused LayerNorms, 0 stand-alone launches, -1 switched off by the fall-back budget (vitx_ctx_ln_fusion_active)."""
+        return int(lib().vitx_ctx_ln_fusion_active(self._h))
 
     def stream_retries(self) -> int:
         """Internal sub-batch streams re-created because they did not run beside the caller's stream (vitx_ctx_stream_retries)."""

@@ -105,7 +105,13 @@ def convert_timm_state_dict(sd, path: str, ftype: int = 1, heads: int = 0, id2la
     g = int(round((n_tok - 1) ** 0.5))
     if Dw != D or P != P2 or g * g + 1 != n_tok or cin not in (1, 3):
         raise ValueError(f"unexpected shapes: patch kernel {t['patch_embed.proj.weight'].shape}, pos_embed {t['pos_embed'].shape}")
-    H = heads or D // 64
+    # The head count is NOT in a state_dict (the reference reads timm's module attribute, convert-pth-to-ggml.py): it is only inferred for
+    # the widths of timm's released ViTs, where it is unambiguous; any other width needs --heads (r03 advisor: D // 64 silently turned
+    # ViT-H/14's 16 heads of 80 into 20 heads of 64 -- a file that loads, runs and is wrong).
+    _TIMM_HEADS = {192: 3, 384: 6, 768: 12, 1024: 16, 1280: 16, 1152: 16, 1408: 16, 1664: 16}      # tiny, small, base, large, huge, so400m, giant, gigantic
+    H = heads or _TIMM_HEADS.get(D, 0)
+    if H <= 0:
+        raise ValueError(f"hidden size {D} is not a released timm ViT width ({sorted(_TIMM_HEADS)}): pass the head count (--heads)")
     if D % H or (D // H) % 8 or not 8 <= D // H <= 128:
         raise ValueError(f"head_dim {D // H if H and D % H == 0 else '?'}: the forward path takes multiples of 8 up to 128 (pass --heads for a model whose head_dim is not 64)")
     hp = HParams(D, L, H, int(t["head.weight"].shape[0]), int(P), g * int(P), ftype)
@@ -126,7 +132,7 @@ def main(argv=None) -> int:
     ap.add_argument("model"); ap.add_argument("out"); ap.add_argument("--ftype", type=int, default=1, help="0 f32, 1 f16 (default), 2/3/6/7/8 q4_0/q4_1/q5_0/q5_1/q8_0")
     ap.add_argument("--vitstr", action="store_true", help="one-channel ViTSTR scene-text model: write the character set as labels")
     ap.add_argument("--timm-state-dict", action="store_true", help="`model` is a torch-saved timm VisionTransformer state_dict (.pth); no timm import needed")
-    ap.add_argument("--heads", type=int, default=0, help="attention heads of a timm checkpoint (default hidden / 64)")
+    ap.add_argument("--heads", type=int, default=0, help="attention heads of a timm checkpoint (inferred only for the widths of released timm ViTs; required otherwise)")
     ap.add_argument("--labels", default=None, help="JSON file {class id: label} for a timm checkpoint (default: none are written)")
     a = ap.parse_args(argv)
     if a.timm_state_dict:

@@ -112,6 +112,14 @@ struct vitx_ctx {
     unsigned ln_epoch = 0;               // tag of the next fused launch (unique per launch; 0 is never used)
     unsigned ln_timeout = 20000;         // 200 us of the 100 MHz wall clock before a workgroup leaves its tile to the fix-up
     int ln_test = 0;                     // vitx_ctx_options::ln_test (parity tests: forced time-outs, GemmLn::test)
+    // Fall-back budget (r03 advisor): a fused tile whose peers do not answer stalls up to ln_timeout per polled peer before it leaves its row block to
+    // the consumer -- correct, but a throughput cliff when the peers' CUs are held by someone else (a second context, another process).  Every
+    // forward copies the slices' fall-back counters to pinned host memory (asynchronously: the values read here are one forward old); more than
+    // kLnBudget tiles per forward on average over a window of kLnWindow forwards switches the fusion off for this context (same bits either way).
+    unsigned *ln_fb_host = nullptr;      // [nslices] pinned
+    unsigned long long ln_fb_base = 0;   // counter total at the start of the current window
+    int ln_fb_forwards = 0;
+    bool ln_fuse_disabled = false;       // the budget tripped (vitx_ctx_ln_fusion_active)
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
     // (measured +10 % images/s at batch 256, tools/two_stream_probe.py).  Sub-batches are independent images.
@@ -172,6 +180,7 @@ struct vitx_ctx {
         if (probe_a) (void)hipEventDestroy(probe_a);
         if (probe_b) (void)hipEventDestroy(probe_b);
         if (prof_base) (void)hipEventDestroy(prof_base);
+        if (ln_fb_host) (void)hipHostFree(ln_fb_host);
         if (trace_buf) (void)hipFree(trace_buf);
         for (void *p : allocs) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
@@ -280,7 +289,7 @@ struct ProfScope {
 // row blocks that GEMM left behind, they are fixed by a launch of their own first.
 int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const void *A, const void *W, const float *bias, void *out, const float *pos,
          int M, int M_real, int N, int N_pad, int K, int lda, int ldw, int ldo, int tpi, size_t out_elem_bytes, const QuantW *fused = nullptr, const GemmLn *ln = nullptr,
-         const GemmLn *fix = nullptr, long hilo_off = 0) {
+         const GemmLn *fix = nullptr, long hilo_off = 0, int rows_alg = 0) {
     GemmArgs a{};
     a.A = A; a.W = W; a.bias = bias; a.out = out; a.pos = pos; a.hilo_off = hilo_off;
     a.M = M; a.M_real = M_real; a.N = N; a.N_pad = N_pad; a.K = K; a.lda = lda; a.ldw = ldw; a.ldo = ldo; a.tpi = tpi;
@@ -292,11 +301,14 @@ int gemm(vitx_ctx *c, const Tuning &tune, hipStream_t st, int pc, int epi, const
             HIP_TRY(launch_layernorm_fixup(c->dtype, fix->x, fix->w, fix->b, fix->out, M, K, fix->eps, fix->todo, fix->epoch, st));
         }
     }
-    double bytes = (double)M_real * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_real * N * out_elem_bytes;
-    if (epi == EPI_BIAS_RESID) bytes += (double)M_real * N * 4;
-    if (epi == EPI_BIAS_HILO) bytes += (double)M_real * N * out_elem_bytes;        // the second plane
-    if (ln) bytes += (double)M_real * N * 2;
-    ProfScope ps(c, st, pc, 2.0 * M_real * (double)N * K, bytes);
+    // algorithmic work of the launch: the REAL rows (a LayerNorm-fusing launch computes and stores its pad rows too -- GemmLn -- but they are not work
+    // the forward asked for: r03 counted them, +0.46 % on the fc2 figure)
+    const int M_alg = rows_alg > 0 ? rows_alg : M_real;
+    double bytes = (double)M_alg * K * 2 + (double)N * K * (fused ? 0.5625 : 2.0) + (double)M_alg * N * out_elem_bytes;
+    if (epi == EPI_BIAS_RESID) bytes += (double)M_alg * N * 4;
+    if (epi == EPI_BIAS_HILO) bytes += (double)M_alg * N * out_elem_bytes;        // the second plane
+    if (ln) bytes += (double)M_alg * N * 2;
+    ProfScope ps(c, st, pc, 2.0 * M_alg * (double)N * K, bytes);
     if (fused) {
         a.W = fused->blocks; a.Wscale = fused->scales;
         HIP_TRY(launch_gemm_q4(c->dtype, epi, a, st));
@@ -350,7 +362,12 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->quant_on_device = !opt.quant_on_host;
     c->q4_fused_rows = opt.q4_fused_rows;
     c->graphs_on = opt.graph != 0;
-    c->ln_test = opt.ln_test; if (opt.ln_test == 3) c->ln_timeout = 5000;      // real time-outs in the test: 50 us
+    // fault injection for the parity tests: honoured only with the key in the upper half (VITX_LN_TEST_KEY | mode), so that no caller sets it by accident
+    if (opt.ln_test) {
+        if ((opt.ln_test & (int32_t)0xffff0000) != (int32_t)VITX_LN_TEST_KEY) { set_error("vitx_ctx_create_ex: ln_test is a test-only switch (VITX_LN_TEST_KEY | mode)"); return VITX_ERR_ARG; }
+        c->ln_test = opt.ln_test & 0xffff;
+        if (c->ln_test == 3) c->ln_timeout = 5000;       // real time-outs in the test: 50 us
+    }
     c->ln_fuse = !opt.no_ln_fusion && !opt.graph;        // a captured launch would replay its epoch tag: no fusion under the graph cache
 #ifdef VITX_LAB
     if (const char *e = getenv("VITX_SKIP")) c->skip = atoi(e);
@@ -461,6 +478,8 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
         }
     }
     if (ns > 1) HIP_TRY(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void **)&c->ln_fb_host, sizeof(unsigned) * 4, hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) c->ln_fb_host[i] = 0;
     if ((rc = c->dmalloc((void **)&c->img, (size_t)max_batch * c->S * c->S * c->Cin * 4, false))) return rc;
     if ((rc = c->dmalloc((void **)&c->probs, (size_t)max_batch * c->R * c->C * 4, true))) return rc;
     if ((rc = c->dmalloc((void **)&c->logits_all, (size_t)max_batch * c->R * c->C * 4, true))) return rc;
@@ -553,7 +572,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             ln.w = lw; ln.b = lb; ln.x = sl.X; ln.out = ln_out; ln.eps = c->hp.eps; ln.sync = sl.ln_sync; ln.todo = sl.ln_todo; ln.fallbacks = sl.ln_todo + sl.ln_blocks;
             if (++c->ln_epoch == 0) c->ln_epoch = 1;
             ln.epoch = c->ln_epoch; ln.timeout = c->ln_timeout; ln.test = c->ln_test;
-            if ((rc2 = gemm(c, tn_, st, pc, EPI_BIAS_RESID, A, W, bias, sl.X, nullptr, M, M, D, round_up(D, tn), K, K, K, D, 0, 4, nullptr, &ln))) return rc2;
+            if ((rc2 = gemm(c, tn_, st, pc, EPI_BIAS_RESID, A, W, bias, sl.X, nullptr, M, M, D, round_up(D, tn), K, K, K, D, 0, 4, nullptr, &ln, nullptr, 0, M_real))) return rc2;
             *pend = ln;
             return VITX_OK;
         }
@@ -661,6 +680,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         ProfScope ps(c, st, PC_SOFTMAX, 0, (double)nR * c->C * 8);
         HIP_TRY(launch_softmax(dt, lg, (float *)d_probs, nR, c->C, ldl, st));
     }
+    if (fuse && c->ln_fb_host) HIP_TRY(hipMemcpyAsync(c->ln_fb_host + (&sl - &c->slices[0]), sl.ln_todo + sl.ln_blocks, sizeof(unsigned), hipMemcpyDeviceToHost, st));       // fall-back budget
     return VITX_OK;
 }
 
@@ -814,6 +834,15 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     if (n <= 0 || n > c->max_batch) { set_error("vitx_forward_device: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (c->ln_fuse && c->ln_fb_host && !c->ln_test) {       // fall-back budget of the fused LayerNorm (the counters are what the PREVIOUS forwards copied out)
+        constexpr int kLnWindow = 16, kLnBudget = 8;
+        if (++c->ln_fb_forwards >= kLnWindow) {
+            unsigned long long total = 0;
+            for (int i = 0; i < c->nslices && i < 4; ++i) total += c->ln_fb_host[i];
+            if (total - c->ln_fb_base > (unsigned long long)kLnWindow * kLnBudget) { c->ln_fuse = false; c->ln_fuse_disabled = true; }
+            c->ln_fb_base = total; c->ln_fb_forwards = 0;
+        }
+    }
     // while per-kernel profiling is on, sub-batches run back to back on the caller's stream so that every
     // event pair brackets one kernel running alone (exclusive durations, comparable with rocprofv3 --stats)
     const bool serial = c->prof_on;
@@ -1001,6 +1030,7 @@ int vitx_op_gemm_q4(int dtype, int epi, const void *a, const void *qs, const voi
 size_t vitx_ctx_weight_bytes(const vitx_ctx *c) { return c ? c->weight_bytes : 0; }
 int vitx_ctx_shares_weights(const vitx_ctx *c) { return c && c->weights_shared ? 1 : 0; }
 int vitx_ctx_stream_retries(const vitx_ctx *c) { return c ? c->stream_retries : -1; }
+int vitx_ctx_ln_fusion_active(const vitx_ctx *c) { return c ? ((c->ln_fuse && !c->slices.empty() && c->slices[0].ln_sync && c->tune->n_xcd == 8) ? 1 : (c->ln_fuse_disabled ? -1 : 0)) : 0; }
 long long vitx_ctx_ln_fallbacks(vitx_ctx *c) {
     if (!c) return -1;
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;

@@ -1254,8 +1254,21 @@ hipError_t launch_attention(const Tuning &t, int dtype, const void *qkv, void *o
     if (!attention_supports(N, D, H)) return hipErrorInvalidValue;
     if (D != H * 64) return dtype == DT_F16 ? launch_attention_generic<_Float16>(qkv, out, n_img, N, D, H, stream) : launch_attention_generic<__bf16>(qkv, out, n_img, N, D, H, stream);
     // 193..224 tokens: the persistent single-pass kernel (K/V of the next item by LDS-DMA under the current item's softmax)
-    if ((t.attn_kernel == ATTN_PERSIST || t.attn_kernel == ATTN_AUTO) && attention_persist_supports(n_img, N, D))
-        return dtype == DT_F16 ? launch_attention_persist<_Float16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags) : launch_attention_persist<__bf16>(qkv, out, n_img, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags);
+    if ((t.attn_kernel == ATTN_PERSIST || t.attn_kernel == ATTN_AUTO) && N > 192 && N <= 224) {
+        // 32-bit buffer offsets bound one launch (~4.4 k ViT-B images): a larger sub-batch is cut into several launches of the SAME kernel rather than
+        // handed to another family (whose f32 sums are grouped differently: an image's result must not depend on the batch it arrives in -- r03 advisor)
+        const size_t per_img = (size_t)N * 3 * D * 2;
+        const int max_img = (int)std::min<size_t>((size_t)n_img, (0xf0000000u - 1) / per_img);
+        if (max_img < 1) return hipErrorInvalidValue;
+        for (int i0 = 0; i0 < n_img; i0 += max_img) {
+            const int ni = std::min(max_img, n_img - i0);
+            const char *q = (const char *)qkv + (size_t)i0 * per_img; char *o = (char *)out + (size_t)i0 * N * D * 2;
+            const hipError_t e = dtype == DT_F16 ? launch_attention_persist<_Float16>(q, o, ni, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags)
+                                                 : launch_attention_persist<__bf16>(q, o, ni, N, D, H, t.attn_grid > 0 ? t.attn_grid : t.n_cu, stream, t.attn_flags);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     if (t.attn_kernel == ATTN_PERSIST) return hipErrorInvalidValue;
     if (t.attn_kernel == ATTN_STREAM) return launch_attention_stream(dtype, false, qkv, out, n_img, N, D, H, 0, stream);
     const bool single = attention_single_pass_supports(N) && (N <= 288 || t.attn_kernel == ATTN_SINGLE);
