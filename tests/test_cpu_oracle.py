@@ -156,6 +156,31 @@ def test_oracle_summation_order_noise_floor(pkg, oracle):
     assert (p0.argmax(1) == p1.argmax(1)).all()
 
 
+def test_q8_0_activation_semantics_are_not_reproducible_to_1e3(pkg, oracle, tmp_path):
+    """DESIGN.md section 7, the measured reason the engine has no 'quant_act' mode (r03 verdict item 6): ggml quantises the ACTIVATIONS of a
+    quantised-weight mul_mat to q8_0 blocks (one scale per 32 values, round to 8 bits).  A 1e-7 perturbation -- here: the f32 summation order of the
+    attention / patch-embedding dots, the only f32 dots left in that graph -- flips 8-bit roundings in every later layer.  The reference's q4_0 graph
+    therefore differs from ITSELF by more than the 1e-3 the path is held to, an order of magnitude more than its f16 graph does; no device
+    implementation of that semantics (i8 MFMA or otherwise) could be certified against it at 1e-3, so the engine keeps dequantised weights x
+    16-bit activations and the tests report the distance to both semantics."""
+    name = "vit_tiny_patch16_224"
+    pf = pkg.synth.cached_synthetic(name, head_scale=8.0)
+    pq = str(tmp_path / "q4_0.gguf")
+    pkg.synth.write_synthetic(pq, name, ftype=2, head_scale=8.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(8, 224))
+    exact = dataclasses.replace(oracle.REF, dot_exact=1)
+    om = oracle.OracleModel(pf)
+    noise_f16 = np.abs(om.forward(imgs, oracle.REF)[1] - om.forward(imgs, exact)[1]).max()
+    om = oracle.OracleModel(pq)
+    p_ref = om.forward(imgs, oracle.REF)[1]
+    noise_q = np.abs(p_ref - om.forward(imgs, exact)[1]).max()
+    to_dequantised = np.abs(p_ref - om.forward(imgs, dataclasses.replace(oracle.REF, quant_act=0))[1]).max()
+    print("q8_0 activation semantics: self-noise f16 graph %.3e, q4_0 graph %.3e; q4_0 graph vs dequantised-weight semantics %.3e" % (noise_f16, noise_q, to_dequantised))
+    assert noise_f16 < 5e-4
+    assert noise_q > 1e-3 and noise_q > 5 * noise_f16
+    assert to_dequantised < 4 * noise_q          # the two semantics are as far apart as the reference is from itself
+
+
 @pytest.mark.parametrize("ftype", [2, 3, 6, 7, 8])
 def test_oracle_quantised_weights(pkg, oracle, ftype, tmp_path):
     """q4_0/q4_1/q5_0/q5_1/q8_0 files load and run with ggml's q8 activation quantisation; results stay close to f16."""

@@ -1,18 +1,20 @@
 // attention_stream.hip -- streaming two-pass attention for gfx950 (vit.cpp:826-866), any token count, head dim 64.
 //
 // Two builds of one kernel:
-//   * fast  (QT = 2, PREC = false; f16 or bf16 operands): the long-sequence kernel (577 tokens of ViT-L/16-384).  r03's pipelined kernel
-//     (attention_flow_kernel, kernels.hip) ran 0.20 of the MFMA peak: 32x32x16 products, a vmcnt(0) + __syncthreads per 64-key chunk and
-//     compiler-scheduled LDS reads that drain the in-flight LDS-DMA.  Here: v_mfma_f32_16x16x32 (the GEMMs' instruction), a wave owns
-//     TWO 16-query tiles so every K / V^T fragment read from LDS feeds two products (one fragment per product is exactly the LDS peak:
-//     1 KiB per 16-cycle MFMA per SIMD = 256 B/clk/CU), a THREE-slot ring of 64-key chunks filled by LDS-DMA two chunks ahead with
-//     counted vmcnt and one raw barrier per chunk, every LDS read inline asm with counted lgkmcnt, row reductions by permlane swaps,
-//     16-byte output stores; <= 128 VGPRs and 48 KiB of LDS, so two workgroups (16 waves) share a CU.
+//   * fast  (QT = 2, PREC = false; f16 or bf16 operands): built as the r03 verdict's long-sequence kernel (577 tokens of ViT-L/16-384) --
+//     v_mfma_f32_16x16x32 (the GEMMs' instruction), a wave owns TWO 16-query tiles so every K / V^T fragment read from LDS feeds two products
+//     (one fragment per product is exactly the LDS peak: 1 KiB per 16-cycle MFMA per SIMD = 256 B/clk/CU), a three-slot ring of 64-key chunks
+//     filled by LDS-DMA two chunks ahead with counted vmcnt and one raw barrier per chunk, every LDS read inline asm with counted lgkmcnt, row
+//     reductions by permlane swaps, 16-byte output stores; 16 waves x 128 VGPRs.  MEASURED SLOWER than attention_flow_kernel at 577 tokens
+//     (250 vs 212 us, profiles/r04/attention_577_ablation.txt): it is kernel id 5 (tests, lab) and NOT what the forward runs in bf16.
 //   * precise (QT = 1, PREC = true; f16 only): the F16 PARITY MODE at every token count.  The reference multiplies f32 q, k, v
 //     (ggml_mul_mat on f32 views, vit.cpp:848,858); r03 rounded them to fp16 for the MFMAs -- the one known semantic deviation of that
 //     mode.  Here q, k, v arrive as TWO fp16 planes from the QKV GEMM (EPI_BIAS_HILO: hi = round(x), lo = round((x - hi) * 2048)) and
 //     every product is three MFMAs, hi.hi + (hi.lo + lo.hi) / 2048 (the dropped lo.lo term is 2^-22 relative): f32-grade scores; the
 //     probabilities are the fp16 exp-table values (exact in fp16, as ggml's LUT emits them), so P.V needs only V split: two MFMAs.
+//     193..224 tokens: RES = 13 / 14 score tiles stay in registers between ONE K stream and the V stream (16 waves x 128 VGPRs);
+//     other token counts: two passes, 8 waves x 256 VGPRs.
+// Every build claims the whole register file of its SIMDs (AS_CLAIM below): a foreign wave beside this MFMA stream computed wrong DPP sums.
 // Both: pass 1 streams K for the row maxima of the raw scores, pass 2 streams K and V: e = AttnExp<T>(s, max) (F16: ggml_soft_max's
 // table semantics), row sum of the rounded numerators, O^T = V^T . P^T, O / sum rounded once to the operand type.
 // Keys past N inside the last chunk read the next image's rows (finite; masked to -inf, probability exactly 0) or the zeros a buffer
