@@ -62,6 +62,11 @@ def measure_traffic(model, batch, dtype, timeout=150):
         import hbm_traffic as HT
     except Exception as e:
         return None, f"tools/hbm_traffic.py not importable: {e}"
+    # bench.py itself under a profiler (rocprofv3 -- python bench.py, as the round's kernel-trace summary is taken): a nested counter pass would
+    # inherit the tool's preload and fight it for the counters -- the outer trace is the record then, and traffic stays null
+    prof_env = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER"))] + [k for k in ("LD_PRELOAD",) if "rocprof" in os.environ.get(k, "")]
+    if prof_env:
+        return None, "not measured: bench.py is itself running under a profiler (" + ", ".join(sorted(prof_env)[:3]) + ")"
     tmp = tempfile.mkdtemp(prefix="vitx_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if not k.startswith(("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_"))}
     env["TMPDIR"] = "/tmp"
