@@ -138,7 +138,8 @@ typedef struct vitx_ctx_options {
     int32_t split_first;      /* with 2 streams: images of the first sub-batch (default 0 = the tile-round model decides) */
     int32_t no_ln_fusion;     /* 1: every LayerNorm runs as its own kernel (default: norm2 / the next norm1 ride in the proj / fc2 GEMMs) */
     int32_t ln_test;          /* parity tests only, honoured only as VITX_LN_TEST_KEY | mode (anything else is refused): mode 1 = every fifth tile of a LayerNorm-fusing GEMM behaves as if a peer had timed out, 3 = and withholds its
-                                 statistics (real 50 us time-outs): the consumer-side fix-up must then give the same bits */
+                                 statistics (real 50 us time-outs): the consumer-side fix-up must then give the same bits; | 4 = the forced fall-backs count against the
+                                 fall-back budget (without it a test context keeps fusing whatever the count) */
     int32_t f16_fast_attention; /* VITX_F16 contexts: 1 = q, k, v rounded to fp16 for the attention products (the r03 behaviour: one QKV plane, the fast
                                  attention kernels) instead of the parity mode's f32-grade products (two fp16 planes, three MFMAs per product) */
 } vitx_ctx_options;

@@ -291,6 +291,34 @@ def test_ln_test_switch_needs_its_key_and_fusion_is_reported(pkg, binding, torch
     a.close(); b.close(); model.close()
 
 
+def test_ln_fallback_budget_switches_the_fusion_off(pkg, binding, torch_gpu):
+    """A context whose column-tile peers keep missing each other (a partitioned or shared device: here every fifth tile forced, ln_test bit 4 =
+    the forced fall-backs count) must not spin for the time-out in every launch forever: after a window of 16 forwards with more than 8 fix-up
+    tiles each the context runs stand-alone LayerNorms for good (r03 advisor).  Same bits before and after, and as a context that never fused."""
+    torch = torch_gpu
+    name, n = "vit_base_patch16_224", 256            # sub-batches wide enough for the fusing kernel
+    path = pkg.synth.cached_synthetic(name, head_scale=8.0)
+    hp = pkg.synth.hparams_for(name)
+    imgs = torch.randn((n, hp.img_size, hp.img_size, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(11))
+    model = binding.Model(path)
+    plain = binding.Context(model, max_batch=n, dtype=binding.BF16, no_ln_fusion=1)
+    ctx = binding.Context(model, max_batch=n, dtype=binding.BF16, ln_test=binding.LN_TEST_KEY | 5)
+    ref = torch.empty((n, hp.num_classes), device="cuda"); probs = torch.empty_like(ref)
+    plain.forward_device(imgs.data_ptr(), n, ref.data_ptr(), 0, 0); plain.synchronize()
+    assert ctx.ln_fusion_active() == 1
+    states = []
+    for rep in range(40):
+        ctx.forward_device(imgs.data_ptr(), n, probs.data_ptr(), 0, 0); ctx.synchronize()
+        assert torch.equal(probs, ref), rep
+        states.append(ctx.ln_fusion_active())
+    assert states[0] == 1 and states[-1] == -1 and states.index(-1) <= 34, states          # off at the first or second window boundary
+    before = ctx.ln_fallbacks()
+    assert before > 16 * 8
+    ctx.forward_device(imgs.data_ptr(), n, probs.data_ptr(), 0, 0); ctx.synchronize()
+    assert ctx.ln_fallbacks() == before and torch.equal(probs, ref)                          # no fusing launch any more
+    ctx.close(); plain.close(); model.close()
+
+
 @pytest.mark.parametrize("ln_test", [1, 3])
 @pytest.mark.parametrize("name,n", [("vit_base_patch16_224", 256), ("vit_large_patch16_384", 70)])
 def test_forward_ln_fallback_fixed_by_the_consumer_gemm(pkg, binding, torch_gpu, name, n, ln_test):
