@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -576,8 +577,16 @@ static hipError_t launch_attention_t(const void *qkv, void *out, int n_img, int 
 // (finite values; their scores are masked to -inf and their probabilities are exactly 0) or, past the end of the tensor, the
 // zeros a buffer load returns out of range.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int FLAGS>      // FLAGS: ablation builds of tools/attn_bench.py (1 no re-staging, 2 no barriers, 4 no exp/convert, 8 no PV, 16 no pass 1); 0 = product
+// ONLINE (r04, bf16 only): ONE pass.  The reference's softmax goes through fp16 tables relative to the TRUE row maximum, which is why the F16
+// builds take the maximum first; bf16 has no rounding point of the reference to reproduce there, and softmax is invariant under the per-row
+// constant that is subtracted, so the bf16 build keeps a RUNNING maximum instead and never streams K a second time (64 images x 16 heads x 577
+// tokens: 211 -> 160 us; ViT-L/16-384 forward +3.5 %, profiles/r04/ab_online_softmax.txt).  The constant is only moved when some row's tile maximum
+// exceeds it by more than kTau (2^8 in the exponent: numerators stay <= 256, exact in bf16's range and harmless in the f32 sums) -- in practice
+// during the first chunks only -- and then the accumulators and the running sum of every lane are rescaled by exp2 of its own shift.
+// Rounding: P is rounded to bf16 at whatever scale it has (a relative rounding), O / sum once at the end, as before.
+template <typename T, int FLAGS, bool ONLINE = false>      // FLAGS: ablation builds of tools/attn_bench.py (1 no re-staging, 2 no barriers, 4 no exp/convert, 8 no PV, 16 no pass 1); 0 = product
 __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restrict__ qkv, T *__restrict__ out, int N, int D, int H, int qblocks, int items, int n_img) {
+    static_assert(!ONLINE || std::is_same<T, __bf16>::value, "the running-maximum schedule is the bf16 build's");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CK = 64, KBYTES = CK * 128, VBYTES = CK * 128, BUF = KBYTES + VBYTES;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -654,14 +663,14 @@ __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restr
         for (int r = 0; r < 16; r += 2) m = fmaxf(fmaxf(s[r], s[r + 1]), m);        // v_max3_f32
     };
 
-    stage(smem, 0, false);
+    stage(smem, 0, ONLINE);
     __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
     __syncthreads();
 
     // ---- pass 1: global row maximum of the raw scores.  Chunk c is computed out of buffer c & 1 while the DMA of chunk c + 1
     // fills the other one; after the last chunk comes chunk 0 of pass 2 (with V).
     float mxs = -INFINITY;
-    for (int c = 0; c < nch; ++c) {
+    for (int c = 0; c < nch && !ONLINE; ++c) {
         const int key0 = c * CK;
         const char *cur = smem + (c & 1) * BUF;
         char *nxt = smem + ((c + 1) & 1) * BUF;
@@ -678,11 +687,11 @@ __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restr
         __builtin_amdgcn_s_waitcnt(0x0f70);
         if (!(FLAGS & 2) || last) __syncthreads();
     }
-    mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
+    if constexpr (!ONLINE) mxs = fmaxf(mxs, __shfl_xor(mxs, 32));
 
-    // ---- pass 2: exponentials against the global maximum, row sum of the ROUNDED values, O^T = V^T P^T
+    // ---- pass 2: exponentials against the global maximum (ONLINE: the running one), row sum of the ROUNDED values, O^T = V^T P^T
     float sum = 0.0f;
-    const float nmx = -AttnExp<T>::kScale * mxs;
+    float nmx = -AttnExp<T>::kScale * mxs;            // ONLINE: mxs = -inf here, nmx is set by the first tile's rescale
     f32x16 o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -733,11 +742,11 @@ __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restr
                 }
         }
     };
+    const int buf0 = ONLINE ? 0 : nch;                // pass 1's last stage filled buffer nch & 1: pass 2's chunk c lives in buffer (nch + c) & 1
     for (int c = 0; c < nch; ++c) {
         const int key0 = c * CK;
-        // pass 1's last stage filled buffer nch & 1: pass 2's chunk c lives in buffer (nch + c) & 1
-        const char *cur = smem + ((nch + c) & 1) * BUF;
-        char *nxt = smem + ((nch + c + 1) & 1) * BUF;
+        const char *cur = smem + ((buf0 + c) & 1) * BUF;
+        char *nxt = smem + ((buf0 + c + 1) & 1) * BUF;
         const bool last = c + 1 == nch;
         if (!last && !(FLAGS & 1)) stage(nxt, key0 + CK, true);
         if (wave_live) {
@@ -746,6 +755,24 @@ __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restr
                 f32x16 s; v8 p[2];
                 qk_tile(cur, kt, s);
                 if (last) mask_tile(kt, key0, s);
+                if constexpr (ONLINE) {
+                    // a processed tile holds at least one real key, so its maximum is finite; the two lanes of a query (key halves hh = 0, 1) see
+                    // the same tile maximum and the same running one, hence the same shift
+                    constexpr float kTau = 8.0f / AttnExp<T>::kScale;
+                    float tm = -INFINITY, u, v;
+                    max_tile(s, tm);
+                    rows_swap32(tm, u, v); tm = fmaxf(u, v);
+                    if (__builtin_amdgcn_ballot_w64(tm > mxs + kTau) != 0) {          // wave-uniform; first tile: mxs = -inf
+                        const float mnew = fmaxf(mxs, tm);
+                        const float sc = __builtin_amdgcn_exp2f((mxs - mnew) * AttnExp<T>::kScale);      // exp2(-inf) = 0 on the first tile
+                        mxs = mnew; nmx = -AttnExp<T>::kScale * mnew;
+                        sum *= sc;
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[dt][r] *= sc;
+                    }
+                }
                 exp_tile(s, p); pv_tile(cur, kt, p);
             }
         }
@@ -769,10 +796,11 @@ __global__ __launch_bounds__(256, 4) void attention_flow_kernel(const T *__restr
 template <typename T, int FLAGS>
 static hipError_t launch_attention_flow_inst(const void *qkv, void *out, int n_img, int N, int D, int H, hipStream_t stream) {
     constexpr int lds = 2 * (64 * 128 + 64 * 128);        // two (8 KiB K + 8 KiB V) chunk buffers
-    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_flow_kernel<T, FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
+    constexpr bool ONLINE = std::is_same<T, __bf16>::value && FLAGS == 0;
+    if (n_img == 0) return hipFuncSetAttribute((const void *)attention_flow_kernel<T, FLAGS, ONLINE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // device bring-up
     const int qblocks = ((N + 31) / 32 + 3) / 4, items = n_img * H;
     const int grid = ((items + 7) / 8) * 8 * qblocks;
-    hipLaunchKernelGGL((attention_flow_kernel<T, FLAGS>), dim3(grid), dim3(256), lds, stream, (const T *)qkv, (T *)out, N, D, H, qblocks, items, n_img);
+    hipLaunchKernelGGL((attention_flow_kernel<T, FLAGS, ONLINE>), dim3(grid), dim3(256), lds, stream, (const T *)qkv, (T *)out, N, D, H, qblocks, items, n_img);
     return hipGetLastError();
 }
 template <typename T>
