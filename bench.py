@@ -527,7 +527,7 @@ def main():
             except Exception as e:
                 out["two_forwards_in_flight"] = {"error": str(e)}
 
-            def secondary(name, batch, ftype_name, dtype_name, steps, warm, n_rows, d_in=None, ctx_opts=None, reuse=None):
+            def secondary(name, batch, ftype_name, dtype_name, steps, warm, n_rows, d_in=None, ctx_opts=None, reuse=None, sustain_s=0.0):
                 """One configuration measured like the primary: warm-up, `steps` timed steps of the production schedule, one profiled step
                 outside the clock (its own roofline), `n_rows` rows of its batch against the oracle (reference semantics + the same-mode oracle)."""
                 import dataclasses
@@ -550,6 +550,11 @@ def main():
                 pr = profiled_step(c_, batch, d_in, torch.empty_like(d_out))
                 roof, table = roofline_of(pr, 1, None, "not measured for this configuration")
                 line["roofline"] = roof; line["kernel_breakdown"] = table
+                if sustain_s > 0:
+                    n_s = max(30, int(sustain_s / (ms * 1e-3)))
+                    with SmiSampler(local_rank) as smi_:
+                        r_s, ms_s = timed_rate(c_, batch, d_in, torch.empty_like(d_out), n_s, warm=0)
+                    line["sustained"] = {"value": round(r_s, 1), "unit": "images/s", "ms_per_step": round(ms_s, 4), "steps": n_s, "seconds": round(n_s * ms_s * 1e-3, 2), "rocm_smi": smi_.summary()}
                 if reuse is not None:            # the primary's rows, reference probabilities and noise floor (same images, same weight file)
                     rows_, rp, nz = reuse
                     line["parity"] = parity_of(np, got_all[rows_], rp, max(BOUND_F16_FLOOR, 2 * nz) if dtype_name == "f16" else max(BOUND_BF16, 10 * nz),
@@ -583,7 +588,7 @@ def main():
                 try:
                     # the SAME rows, reference probabilities and noise floor as the primary's parity object
                     pm = secondary(args.model, B, "f16", "f16", args.steps, args.warmup, 0, d_in=imgs,
-                                   reuse=(oracle_ctx[1], oracle_ctx[3], oracle_ctx[4]) if oracle_ctx is not None else None)
+                                   reuse=(oracle_ctx[1], oracle_ctx[3], oracle_ctx[4]) if oracle_ctx is not None else None, sustain_s=min(args.sustain_s, 4.0))
                     if "parity" in pm and not pm["parity"]["passed"]:
                         failed.append(f"F16 parity mode outside its bound: {pm['parity']['max_dprob_vs_ref']:.3e} > max(1e-3, 2 x noise floor {oracle_ctx[4]:.3e}) or a decided top-1 differs")
                     pm["what"] = "VITX_F16: fp16 MFMA operands, f32-grade attention products, the reference's fp16 exp / GELU rounding points; timed like `value`, profiled like `roofline`"
