@@ -153,7 +153,8 @@ int vitx_ctx_max_batch(const vitx_ctx *c);
 int vitx_ctx_out_rows(const vitx_ctx *c);
 /* How a forward of n images is cut into contiguous sub-batches (one per internal stream): images[i] = size of sub-batch i, in image
  * order; returns the number of sub-batches (1 when the batch runs on one stream), 0 on a bad argument.  Results never depend on the
- * cut; the parity tests use it to pick the images on either side of every stream boundary. */
+ * cut; the parity tests use it to pick the images on either side of every stream boundary.  A batch beyond the kernels' 32-bit buffer window
+ * (ViT-B: 3326 images, 2217 in the F16 parity mode) runs as several passes through the same scratch: the cut reported is the first pass's. */
 int vitx_ctx_split(const vitx_ctx *c, int n, int32_t *images, int max_parts);
 
 /* Forward pass (replaces vit_encode_image + the compute half of vit_predict,

@@ -200,3 +200,52 @@ def test_forward_parity_mode_and_its_fast_attention_option(pkg, binding, oracle,
     _record(test="forward_parity_mode", model=name, images=n, precise_max_dprob=dp, fast_attention_max_dprob=df)
     assert dp <= 1e-3 and df <= 1e-3
     assert (res["precise"].argmax(1) == ref.argmax(1)).all()
+
+
+def test_attention_beyond_one_launch_window_is_chunked_not_rerouted(binding, torch_gpu):
+    """More (image, head) items than the 32-bit buffer offsets of ONE persistent launch cover (~4.4 k ViT-B images): the launcher cuts the batch
+    into several launches of the SAME kernel (r03 advisor: it used to hand the whole batch to another kernel family, whose f32 sums are grouped
+    differently -- an image's result must not depend on the batch it arrives in).  Images on both sides of the cut equal their stand-alone result."""
+    torch = torch_gpu
+    N, H = 197, 12; D = H * 64
+    n_img = 4500                                          # 4500 x 197 x 2304 x 2 B = 4.08 GB > 0xf0000000
+    assert n_img * N * 3 * D * 2 > 0xf0000000
+    g = torch.Generator(device="cuda").manual_seed(4500)
+    qkv = torch.empty((n_img * N, 3 * D), dtype=torch.bfloat16, device="cuda")
+    for i0 in range(0, n_img, 500):                       # filled in pieces: no 8 GB f32 temporary
+        qkv[i0 * N:(i0 + 500) * N] = (torch.randn((500 * N, 3 * D), device="cuda", generator=g) * 0.8).to(torch.bfloat16)
+    out = torch.zeros((n_img * N, D), dtype=torch.bfloat16, device="cuda")
+    binding.check(binding.lib().vitx_op_attention(binding.BF16, qkv.data_ptr(), out.data_ptr(), n_img, N, D, H, None), "attention")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    cut = (0xf0000000 - 1) // (N * 3 * D * 2)             # images of the first launch
+    for first, cnt in ((0, 40), (cut - 20, 40), (n_img - 40, 40)):
+        sub = qkv[first * N:(first + cnt) * N].contiguous()
+        o2 = torch.zeros((cnt * N, D), dtype=torch.bfloat16, device="cuda")
+        binding.check(binding.lib().vitx_op_attention(binding.BF16, sub.data_ptr(), o2.data_ptr(), cnt, N, D, H, None), "attention")
+        torch.cuda.synchronize()
+        assert torch.equal(out[first * N:(first + cnt) * N], o2), first
+
+
+@pytest.mark.parametrize("big,dtype_name", [(5000, "bf16"), (5000, "f16"), (7001, "bf16")])
+def test_forward_of_thousands_of_images_equals_the_batch_256_result(pkg, binding, torch_gpu, big, dtype_name):
+    """288 GB of HBM invite batches the 32-bit byte offsets of the buffer instructions do not cover: QKV of a 2500-image sub-batch is 2.3 GB (r04: the
+    persistent attention kernel's item offset was a signed int -- wrong results from 2366 images per launch on), the MLP hidden tensor of a 3538-image
+    sub-batch 4.3 GB (garbage at batch 10 000).  A pass of the kernels is now bounded by vitx_ctx_create_ex and larger batches run as several passes:
+    every image of a batch of thousands must get the bits it gets in a batch of 256."""
+    torch = torch_gpu
+    name = "vit_base_patch16_224"
+    dt = binding.BF16 if dtype_name == "bf16" else binding.F16
+    path = pkg.synth.cached_synthetic(name, head_scale=8.0); hp = pkg.synth.hparams_for(name)
+    model = binding.Model(path)
+    base = torch.randn((256, hp.img_size, hp.img_size, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    c0 = binding.Context(model, max_batch=256, dtype=dt)
+    p0 = torch.empty((256, hp.num_classes), device="cuda")
+    c0.forward_device(base.data_ptr(), 256, p0.data_ptr(), 0, 0); c0.synchronize(); c0.close()
+    reps = (big + 255) // 256
+    imgs = base.repeat(reps, 1, 1, 1)[:big].contiguous()
+    c1 = binding.Context(model, max_batch=big, dtype=dt)
+    p1 = torch.empty((big, hp.num_classes), device="cuda")
+    c1.forward_device(imgs.data_ptr(), big, p1.data_ptr(), 0, 0); c1.synchronize()
+    assert torch.equal(p1, p0.repeat(reps, 1)[:big])
+    c1.close(); model.close()

@@ -112,6 +112,7 @@ struct vitx_ctx {
     unsigned ln_epoch = 0;               // tag of the next fused launch (unique per launch; 0 is never used)
     unsigned ln_timeout = 20000;         // 200 us of the 100 MHz wall clock before a workgroup leaves its tile to the fix-up
     int ln_test = 0;                     // vitx_ctx_options::ln_test (parity tests: forced time-outs, GemmLn::test)
+    int call_limit = 0;                  // images ONE pass of the kernels takes (32-bit byte offsets into the largest per-slice buffer); larger batches run as several passes
     // Fall-back budget (r03 advisor): a fused tile whose peers do not answer stalls up to ln_timeout per polled peer before it leaves its row block to
     // the consumer -- correct, but a throughput cliff when the peers' CUs are held by someone else (a second context, another process).  Every
     // forward copies the slices' fall-back counters to pinned host memory (asynchronously: the values read here are one forward old); more than
@@ -435,9 +436,20 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->nslices = ns;
     c->slices.resize(ns);
     const size_t hcols = std::max<size_t>((size_t)4 * D, (size_t)c->Kpe_pad);
+    {
+        // The kernels address every activation buffer with 32-bit BYTE offsets (buffer instructions): a sub-batch must keep its largest buffer --
+        // the MLP hidden tensor, or the two QKV planes of the F16 parity mode -- below 0xf0000000 bytes (ViT-B: 3326 images per sub-batch, 2217 in
+        // parity mode).  Batches beyond one such window run as several passes through the same scratch (vitx_forward_device), so max_batch
+        // itself is only bounded by memory.  r04: the guards used to sit in the individual launchers only, and a 10 000-image batch computed garbage.
+        const size_t row_bytes = std::max<size_t>(hcols * 2, (size_t)3 * D * 2 * (c->prec_attn ? 2 : 1));
+        const size_t rows = (size_t)0xf0000000u / row_bytes / 256 * 256;
+        const long per_slice = (long)(rows / c->N);
+        if (per_slice < 1) { set_error("vitx_ctx_create: a single image exceeds the kernels' 32-bit buffer window (%d tokens x %d)", c->N, D); return VITX_ERR_UNSUPPORTED; }
+        c->call_limit = (int)std::min<long>((long)max_batch, per_slice);          // whatever the split of a pass, no sub-batch exceeds the window
+    }
     for (int i = 0; i < ns; ++i) {
         vitx_ctx::Slice &sl = c->slices[i];
-        sl.cap = max_batch;     // every slice can hold the whole batch: the split point is chosen per call (split_batch)
+        sl.cap = std::min(max_batch, c->call_limit);     // every slice can hold a whole pass: the split point is chosen per call (split_batch)
         const size_t Mpad = (size_t)round_up(sl.cap * c->N, c->tm), Bpad = (size_t)round_up(sl.cap * c->R, c->tm);
         if ((rc = c->dmalloc((void **)&sl.X, Mpad * D * 4, true))) return rc;
         if ((rc = c->dmalloc(&sl.U, Mpad * D * 2, true))) return rc;
@@ -448,7 +460,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
             sl.ln_blocks = (int)(Mpad / 256);
         }
         if ((rc = c->dmalloc(&sl.QKV, Mpad * 3 * D * 2 * (c->prec_attn ? 2 : 1), true))) return rc;
-        sl.qkv_lo_off = c->prec_attn ? (long)(Mpad * 3 * D) : 0;
+        sl.qkv_lo_off = c->prec_attn ? (long)(Mpad * 3 * D) : 0;       // capacity; a forward places the lo plane right behind ITS rows (forward_slice)
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
         if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
@@ -493,6 +505,7 @@ int vitx_ctx_max_batch(const vitx_ctx *c) { return c ? c->max_batch : 0; }
 static void split_batch(const vitx_ctx *c, int n, int ns, int *m);
 int vitx_ctx_split(const vitx_ctx *c, int n, int32_t *images, int max_parts) {
     if (!c || !images || max_parts <= 0 || n <= 0 || n > c->max_batch) return 0;
+    n = std::min(n, c->call_limit);              // a batch beyond the kernels' window runs as several passes: this is the first one's cut
     const int ns = (c->nslices > 1 && n >= 8 * c->nslices) ? c->nslices : 1;
     if (ns > max_parts) return 0;
     int m[4] = {n, 0, 0, 0};
@@ -519,6 +532,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     const int Mp_real = n * tpi;                                   // patch rows
     const int M_real = n * N, M = round_up(M_real, tm);            // token rows
     const double eb = 2.0;                                          // operand bytes
+    const long lo_off = c->prec_attn ? (long)M * 3 * D : 0;         // F16 parity mode: the lo plane of q, k, v right behind this sub-batch's hi plane (elements)
 
     // patch embedding (vit.cpp:747-797) in one launch: im2col gather, GEMM, + bias + pos, token scatter, class rows (patch_embed.hip)
     int rc;
@@ -623,13 +637,13 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         constexpr int prec_dbg = 0;
 #endif
         if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, (c->prec_attn && prec_dbg != 2) ? EPI_BIAS_HILO : EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
-                       fix_u.todo ? &fix_u : nullptr, sl.qkv_lo_off))) return rc;
+                       fix_u.todo ? &fix_u : nullptr, lo_off))) return rc;
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * (D / c->H), (double)M_real * (c->prec_attn ? 7 : 4) * D * eb);
             if (!(skip & 1)) {
                 if (c->prec_attn && prec_dbg != 1) {
                     if (prec_dbg == 3) HIP_TRY(hipDeviceSynchronize());          // lab: the attention kernel runs alone on the device
-                    HIP_TRY(launch_attention_stream(dt, true, sl.QKV, sl.U, n, N, D, c->H, sl.qkv_lo_off, st));
+                    HIP_TRY(launch_attention_stream(dt, true, sl.QKV, sl.U, n, N, D, c->H, lo_off, st));
                     if (prec_dbg == 3) HIP_TRY(hipDeviceSynchronize());
                     if (prec_dbg == 4) HIP_TRY(hipStreamSynchronize(st));        // lab: host-side order after it, other stream keeps running
                 }
@@ -829,11 +843,24 @@ static int ensure_concurrent(vitx_ctx *c, hipStream_t st, int ns) {
     return VITX_OK;
 }
 
+static int forward_pass(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, hipStream_t st);
 int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, void *stream) {
     if (!c || !d_imgs || !d_probs) { set_error("vitx_forward_device: NULL argument"); return VITX_ERR_ARG; }
     if (n <= 0 || n > c->max_batch) { set_error("vitx_forward_device: batch %d outside 1..%d", n, c->max_batch); return VITX_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    // one pass of the kernels takes call_limit images (32-bit buffer window, vitx_ctx_create_ex); a larger batch is several passes, back to back on the
+    // caller's stream through the same scratch -- images are independent, so the results are the ones a single pass would give
+    if (n > c->call_limit && !c->trace_ids.empty()) { set_error("vitx_forward_device: the residual-stream trace takes one pass (at most %d images)", c->call_limit); return VITX_ERR_ARG; }
+    for (int i0 = 0; i0 < n; i0 += c->call_limit) {
+        const int ni = std::min(c->call_limit, n - i0);
+        const int rc = forward_pass(c, (const float *)d_imgs + (size_t)i0 * c->S * c->S * c->Cin, ni, (float *)d_probs + (size_t)i0 * c->R * c->C,
+                                    d_logits ? (float *)d_logits + (size_t)i0 * c->R * c->C : nullptr, st);
+        if (rc) return rc;
+    }
+    return VITX_OK;
+}
+static int forward_pass(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, hipStream_t st) {
     if (c->ln_fuse && c->ln_fb_host && (!c->ln_test || (c->ln_test & 4))) {       // fall-back budget of the fused LayerNorm (the counters are what the PREVIOUS forwards copied out; test mode: only with bit 4)
         constexpr int kLnWindow = 16, kLnBudget = 8;
         if (++c->ln_fb_forwards >= kLnWindow) {

@@ -870,7 +870,9 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)qkv, 0, (int)total_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)out_bytes, 0x00020000);
-    auto item_base = [&](int item) { const int b = item / H, h = item - b * H; return (int)(((size_t)b * N * 3 * D + h * 64) * 2); };     // bytes (< 4 GiB: launcher)
+    // bytes (< 4 GiB: launcher) -- UNSIGNED: as an int it went negative beyond 2 GiB and load_q's pointer arithmetic sign-extended it (r04: wrong
+    // results from 2366 ViT-B images per launch on, a fault beyond; found by the chunked-launch test)
+    auto item_base = [&](int item) -> unsigned { const int b = item / H, h = item - b * H; return (unsigned)(((size_t)b * N * 3 * D + h * 64) * 2); };
     // DMA piece it * 1024 + tid of an image is image row (128 it + row of piece tid), same 16-byte slot: ONE per-lane offset per image
     // and an SGPR stride
     int koff0, voff0;
@@ -881,7 +883,7 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
         voff0 = vr * row_bytes + 2 * D * 2 + vs * 16;
     }
     auto stage = [&](int item, char *buf) {
-        const int so = __builtin_amdgcn_readfirstlane(item_base(item));
+        const int so = __builtin_amdgcn_readfirstlane((int)item_base(item));          // the buffer unit takes the SGPR offset as 32 unsigned bits
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + wave * 1024), 16, koff0, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + wave * 1024), 16, voff0, so, 0, 0);
         if (second) {
