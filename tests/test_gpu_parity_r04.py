@@ -227,12 +227,13 @@ def test_attention_beyond_one_launch_window_is_chunked_not_rerouted(binding, tor
         assert torch.equal(out[first * N:(first + cnt) * N], o2), first
 
 
-@pytest.mark.parametrize("big,dtype_name", [(5000, "bf16"), (5000, "f16"), (7001, "bf16")])
-def test_forward_of_thousands_of_images_equals_the_batch_256_result(pkg, binding, torch_gpu, big, dtype_name):
+@pytest.mark.parametrize("big,dtype_name,streams", [(5000, "bf16", 2), (5000, "f16", 2), (7001, "bf16", 2), (3326, "bf16", 1), (2217, "f16", 1)])
+def test_forward_of_thousands_of_images_equals_the_batch_256_result(pkg, binding, torch_gpu, big, dtype_name, streams):
     """288 GB of HBM invite batches the 32-bit byte offsets of the buffer instructions do not cover: QKV of a 2500-image sub-batch is 2.3 GB (r04: the
     persistent attention kernel's item offset was a signed int -- wrong results from 2366 images per launch on), the MLP hidden tensor of a 3538-image
     sub-batch 4.3 GB (garbage at batch 10 000).  A pass of the kernels is now bounded by vitx_ctx_create_ex and larger batches run as several passes:
-    every image of a batch of thousands must get the bits it gets in a batch of 256."""
+    every image of a batch of thousands must get the bits it gets in a batch of 256.  streams = 1 at 3326 / 2217 images: ONE sub-batch that fills the
+    window to the last row block (hidden tensor 4.02 GB, the two F16 QKV planes 4.02 GB)."""
     torch = torch_gpu
     name = "vit_base_patch16_224"
     dt = binding.BF16 if dtype_name == "bf16" else binding.F16
@@ -244,7 +245,7 @@ def test_forward_of_thousands_of_images_equals_the_batch_256_result(pkg, binding
     c0.forward_device(base.data_ptr(), 256, p0.data_ptr(), 0, 0); c0.synchronize(); c0.close()
     reps = (big + 255) // 256
     imgs = base.repeat(reps, 1, 1, 1)[:big].contiguous()
-    c1 = binding.Context(model, max_batch=big, dtype=dt)
+    c1 = binding.Context(model, max_batch=big, dtype=dt, streams=streams)
     p1 = torch.empty((big, hp.num_classes), device="cuda")
     c1.forward_device(imgs.data_ptr(), big, p1.data_ptr(), 0, 0); c1.synchronize()
     assert torch.equal(p1, p0.repeat(reps, 1)[:big])
