@@ -250,3 +250,26 @@ def test_forward_of_thousands_of_images_equals_the_batch_256_result(pkg, binding
     c1.forward_device(imgs.data_ptr(), big, p1.data_ptr(), 0, 0); c1.synchronize()
     assert torch.equal(p1, p0.repeat(reps, 1)[:big])
     c1.close(); model.close()
+
+
+@pytest.mark.parametrize("n", [1, 37])
+def test_forward_with_21843_classes(pkg, binding, oracle, torch_gpu, n):
+    """timm's *_in21k checkpoints carry a 21 843-class head (the reference's converter writes whatever the checkpoint has): the classifier GEMM runs
+    86 column tiles with a ragged last one and the class softmax spans 21 843 columns -- against the oracle in both operand types."""
+    name = "vit_micro_c21843_patch16_64"
+    path = pkg.synth.cached_synthetic(name, head_scale=8.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(n, 64, seed=21))
+    om = oracle.OracleModel(path)
+    _, rp = om.forward(imgs, oracle.REF)
+    _, bp = om.forward(imgs, oracle.GPU_BF16)
+    model = binding.Model(path)
+    assert model.num_classes == 21843 and model.label(21842) is not None
+    for dt, ref, tol in ((binding.F16, rp, 1e-3), (binding.BF16, bp, 6e-3)):
+        ctx = binding.Context(model, max_batch=n, dtype=dt)
+        probs = ctx.forward(imgs); ctx.close()
+        assert probs.shape == (n, 21843) and np.isfinite(probs).all()
+        assert np.abs(probs.sum(1) - 1).max() < 1e-4
+        assert np.abs(probs - ref).max() <= tol
+        picked = ref[np.arange(n), probs.argmax(1)]              # the class the engine ranks first is (within the tolerance) the reference's best
+        assert (picked >= ref.max(1) - 2 * tol).all()
+    model.close()

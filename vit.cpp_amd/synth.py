@@ -21,6 +21,7 @@ CONFIGS = {
     # name: (hidden, layers, heads, classes, patch, img)
     "vit_micro_patch16_64": (128, 2, 2, 10, 16, 64),       # test-only toy (N=17)
     "vit_micro_c37_patch16_64": (128, 2, 2, 37, 16, 64),   # test-only toy with an ODD class count (the head GEMM's last column group is ragged)
+    "vit_micro_c21843_patch16_64": (128, 2, 2, 21843, 16, 64),   # test-only toy with ImageNet-21k's class count (timm *_in21k heads): 86 column tiles of the head GEMM, a 21843-wide class softmax
     "vit_micro_patch8_224": (128, 2, 2, 10, 8, 224),       # test-only toy with the token count of the reference's default hparams (N=785)
     "vit_micro_hd32_patch16_64": (128, 2, 4, 10, 16, 64),  # test-only toys with head dims other than 64 (the generic attention kernel): 32,
     "vit_micro_hd96_patch16_96": (192, 2, 2, 10, 16, 96),  #   96 (N = 37),
