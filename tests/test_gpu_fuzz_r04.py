@@ -1,0 +1,62 @@
+"""Randomly drawn architectures (seeded: the same 48 every run) through the whole forward, against the oracle.
+
+The reference is generic in every hparam (vit.h:20-37: hidden size, depth, heads, classes, patch and image size) and its converter writes whatever a timm
+checkpoint has; the fixed fixtures of the other modules sit on the headline shapes.  This module walks the space between them: widths of every
+LayerNorm instantiation, head dims 64 (tuned kernels, f32-grade attention in F16 mode) and others (generic kernel), token counts on both sides
+of every kernel boundary (<= 192, 193..224, 225..288, > 288), ragged class counts, batches that do and do not split into sub-batches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+WIDTHS = [64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 768, 896, 1024, 1152, 1280]
+
+
+def draw(seed):
+    r = np.random.RandomState(1000 + seed)
+    D = int(r.choice(WIDTHS))
+    heads = [h for h in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 18, 20) if D % h == 0 and (D // h) % 8 == 0 and 8 <= D // h <= 128]
+    if r.rand() < 0.6 and D % 64 == 0:
+        H = D // 64
+    else:
+        H = int(r.choice(heads))
+    P = int(r.choice([8, 14, 16, 32]))
+    g = int(r.choice([1, 2, 3, 5, 7, 13, 14, 15, 16, 17])) if P >= 14 else int(r.choice([2, 4, 9, 14, 15]))
+    L = int(r.choice([1, 2, 3]))
+    C = int(r.choice([2, 10, 37, 100, 1000, 1001]))
+    n = int(r.choice([1, 2, 3, 5, 17, 33]))
+    ftype = 1
+    if seed >= 24:                                            # the second half: longer sequences (the pipelined kernels), other file types
+        g = int(r.choice([3, 14, 17, 18, 19, 20, 24])) if P >= 14 else int(r.choice([14, 18, 24]))
+        ftype = int(r.choice([1, 1, 0, 2, 3, 6, 7, 8]))      # f16, f32, q4_0, q4_1, q5_0, q5_1, q8_0
+        if D >= 768: L = 1
+    if g * g + 1 > 300 or D >= 1024: n = min(n, 3)          # keep the oracle in seconds
+    return (D, L, H, C, P, g * P), n, ftype
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_architecture_vs_oracle(pkg, binding, oracle, torch_gpu, seed):
+    import dataclasses
+    cfg, n, ftype = draw(seed)
+    name = "fuzz_%d" % seed
+    pkg.synth.CONFIGS[name] = cfg
+    D, L, H, C, P, S = cfg
+    path = pkg.synth.cached_synthetic(name, ftype=ftype, head_scale=4.0)
+    imgs = pkg.synth.normalize_u8(pkg.synth.synthetic_images_u8(n, S, seed=seed))
+    om = oracle.OracleModel(path)
+    REF = dataclasses.replace(oracle.REF, quant_act=0)       # quantised files: the dequantised-weight semantics the engine implements
+    _, rp = om.forward(imgs, REF)
+    _, bp = om.forward(imgs, oracle.GPU_BF16)
+    _, xp = om.forward(imgs, dataclasses.replace(REF, dot_exact=1))
+    noise = float(np.abs(xp - rp).max())
+    model = binding.Model(path)
+    for dt, ref, tol in ((binding.F16, rp, max(1e-3, 3 * noise)), (binding.BF16, bp, max(8e-3, 10 * noise))):
+        ctx = binding.Context(model, max_batch=max(n, 16), dtype=dt)
+        probs = ctx.forward(imgs)
+        again = ctx.forward(imgs)
+        ctx.close()
+        assert np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-4, cfg
+        assert np.array_equal(probs, again), cfg
+        d = float(np.abs(probs - ref).max())
+        assert d <= tol, (cfg, n, ftype, "f16" if dt == binding.F16 else "bf16", d, tol, noise)
+    model.close()
