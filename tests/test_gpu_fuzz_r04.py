@@ -88,3 +88,32 @@ def test_every_batch_size_gives_every_image_its_batch_1_bits(pkg, binding, torch
         assert torch.equal(out[:n], ref[:n]), (n, ctx.split(n))
         assert float(out[n:].max()) == -1.0 if n < nmax else True          # nothing written past the batch
     ctx.close(); model.close()
+
+
+def test_five_models_in_flight_stay_repeatable(pkg, binding, torch_gpu):
+    """Five contexts of four models and both operand types, each on its own caller stream, all in flight at once, 80 rounds: every forward must
+    return the bits the context produced alone.  (r04 found a co-residency hazard between an MFMA-streaming kernel with spare registers and another
+    stream's DPP reductions -- profiles/r04/coresidency_layernorm.txt; with several models in flight far more kernel pairs meet on a SIMD than
+    the two sub-batches of one forward produce.)"""
+    torch = torch_gpu
+    specs = [("vit_base_patch16_224", 64, binding.BF16), ("vit_large_patch16_384", 16, binding.BF16), ("vit_tiny_patch16_224", 64, binding.F16),
+             ("vit_base_patch16_224", 48, binding.F16), ("vit_small_patch16_224", 200, binding.BF16)]
+    live = []
+    for name, n, dt in specs:
+        path = pkg.synth.cached_synthetic(name, head_scale=8.0); hp = pkg.synth.hparams_for(name)
+        m = binding.Model(path); c = binding.Context(m, max_batch=n, dtype=dt)
+        imgs = torch.randn((n, hp.img_size, hp.img_size, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(n))
+        ref = torch.empty((n, hp.num_classes), device="cuda"); out = torch.empty_like(ref)
+        c.forward_device(imgs.data_ptr(), n, ref.data_ptr(), 0, 0); c.synchronize()
+        live.append(dict(m=m, c=c, imgs=imgs, ref=ref, out=out, n=n, st=torch.cuda.Stream(), name=name))
+    torch.cuda.synchronize()
+    for it in range(80):
+        for x in live:
+            with torch.cuda.stream(x["st"]):
+                x["out"].zero_()
+            x["c"].forward_device(x["imgs"].data_ptr(), x["n"], x["out"].data_ptr(), 0, x["st"].cuda_stream)
+        torch.cuda.synchronize()
+        for x in live:
+            assert torch.equal(x["out"], x["ref"]), (x["name"], x["n"], it)
+    for x in live:
+        x["c"].close(); x["m"].close()
