@@ -187,7 +187,9 @@ def test_attention_f16_on_non_representable_inputs(binding, oracle, torch_gpu):
     """ggml's attention products are f32 x f32 (vit.cpp:848,858); the engine feeds fp16 MFMA operands, i.e. it rounds q, k, v.
     With f32 inputs that are NOT fp16-representable the deviation is visible and bounded: the oracle in REF mode (f32 q, k, v)
     vs the engine given the same values rounded on upload -- the difference must stay at the fp16-operand noise level, and the
-    oracle told to round q, k, v (GPU_F16 mode) must be closer still."""
+    oracle told to round q, k, v (GPU_F16 mode) must be closer still.
+    (r04: this is the `f16_fast_attention` path now.  A default F16 context multiplies q, k, v at f32 grade -- the same inputs through that path:
+    tests/test_gpu_parity_r04.py::test_attention_precise_on_non_representable_inputs, 1.2e-4 / 9.9e-6 against 1.8e-4 / 2.7e-5 here.)"""
     torch = torch_gpu
     n_img, N, H = 2, 197, 4; D = H * 64
     rng = np.random.default_rng(42)
