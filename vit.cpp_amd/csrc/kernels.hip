@@ -819,6 +819,9 @@ static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, i
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef PERSIST_SUM_MFMA
+#define PERSIST_SUM_MFMA 1
+#endif
 // Persistent single-pass attention (vit.cpp:826-866) for 193..224 tokens -- ViT-*/16 at 224^2, the headline configuration.
 //   * one persistent workgroup per CU, SIXTEEN waves (four per SIMD), walks (image, head) items; wave w owns the 16 queries 16 w .. 16 w + 15
 //     of the item (197 tokens: 13 waves compute, three only move data).  A wave issues its softmax arithmetic in order, about one
@@ -1004,16 +1007,15 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
 #pragma unroll
                 for (int ks = 0; ks < NKT; ++ks) {      // numerators per AttnExp<T>; row sum of the ROUNDED values (they are what the PV product sees)
                     const v2 e0 = AttnExp<T>::pair(s[2 * ks][0], s[2 * ks][1], nmx), e1 = AttnExp<T>::pair(s[2 * ks][2], s[2 * ks][3], nmx);
-                    sum2[0] = Pair<T>::sum2(e0, sum2[0]); sum2[0] = Pair<T>::sum2(e1, sum2[0]);
+                    if (!PERSIST_SUM_MFMA) { sum2[0] = Pair<T>::sum2(e0, sum2[0]); sum2[0] = Pair<T>::sum2(e1, sum2[0]); }
                     v2 e2 = __builtin_bit_cast(v2, 0u), e3 = __builtin_bit_cast(v2, 0u);       // (an odd last tile: these slots are not multiplied)
                     if (2 * ks + 1 < NT16V) {
                         e2 = AttnExp<T>::pair(s[2 * ks + 1][0], s[2 * ks + 1][1], nmx); e3 = AttnExp<T>::pair(s[2 * ks + 1][2], s[2 * ks + 1][3], nmx);
-                        sum2[1] = Pair<T>::sum2(e2, sum2[1]); sum2[1] = Pair<T>::sum2(e3, sum2[1]);
+                        if (!PERSIST_SUM_MFMA) { sum2[1] = Pair<T>::sum2(e2, sum2[1]); sum2[1] = Pair<T>::sum2(e3, sum2[1]); }
                     }
                     p[ks] = v8{e0[0], e0[1], e1[0], e1[1], e2[0], e2[1], e3[0], e3[1]};
                 }
-                const float sum = rows4_sum(sum2[0] + sum2[1]);
-                inv = 1.0f / sum;
+                if (!PERSIST_SUM_MFMA) { const float sum = rows4_sum(sum2[0] + sum2[1]); inv = 1.0f / sum; }
             }
             VITX_STAMP(2)
             // O^T = V^T . P^T: rows = head dims (4 tiles of 16), cols = queries; V^T fragments by transposed LDS reads, the reads of key
@@ -1021,6 +1023,11 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
             f32x4 o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            // PERSIST_SUM_MFMA: the row sums come out of the matrix pipe -- a fifth "head-dim tile" whose V^T rows are all ones gives every lane the sum of
+            // ITS query's rounded numerators (exact products with 1.0, f32 accumulation) -- instead of 26 v_dot2c per wave and item plus the cross-lane sum
+            f32x4 osum = {0.0f, 0.0f, 0.0f, 0.0f};
+            const unsigned one2 = std::is_same<T, __bf16>::value ? 0x3f803f80u : 0x3c003c00u;
+            const s8 ones8 = __builtin_bit_cast(s8, (u32x4_t{one2, one2, one2, one2}));
             s4 f[2][4][2];
             constexpr bool HALF = (NT16V & 1) != 0;         // the last key step holds one 16-key tile
             auto read_v = [&](int ks) {
@@ -1050,6 +1057,10 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[c][0][0]), "+v"(f[c][0][1]), "+v"(f[c][1][0]), "+v"(f[c][1][1]),
                                                           "+v"(f[c][2][0]), "+v"(f[c][2][1]), "+v"(f[c][3][0]), "+v"(f[c][3][1]));
                 }
+                if (PERSIST_SUM_MFMA && !(FLAGS & 1)) {
+                    if (HALF && ks == NKT - 1) { const s8 pk = __builtin_bit_cast(s8, p[ks]); osum = Elem<T>::mfma16k16(s4{ones8[0], ones8[1], ones8[2], ones8[3]}, s4{pk[0], pk[1], pk[2], pk[3]}, osum); }
+                    else osum = Elem<T>::mfma16(__builtin_bit_cast(v8, ones8), p[ks], osum);
+                }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     if (HALF && ks == NKT - 1) {
@@ -1063,6 +1074,7 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
                     o[dt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p[ks], o[dt]);
                 }
             }
+            if (PERSIST_SUM_MFMA && !(FLAGS & 1)) inv = 1.0f / osum[0];            // every row of the ones tile holds the query's sum
             VITX_STAMP(3)
             // lane (l15 = query, g4) holds O[query][dt * 16 + 4 g4 .. + 3].  v_permlane16_swap: the even lane row gives its odd tile and
             // takes the odd row's even tile -> 8 consecutive dims per lane, two 16-byte stores per wave, each covering whole 64-byte
