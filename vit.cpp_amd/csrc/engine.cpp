@@ -365,7 +365,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->graphs_on = opt.graph != 0;
     // fault injection for the parity tests: honoured only with the key in the upper half (VITX_LN_TEST_KEY | mode), so that no caller sets it by accident
     if (opt.ln_test) {
-        if ((opt.ln_test & (int32_t)0xffff0000) != (int32_t)VITX_LN_TEST_KEY) { set_error("vitx_ctx_create_ex: ln_test is a test-only switch (VITX_LN_TEST_KEY | mode)"); return VITX_ERR_ARG; }
+        if ((opt.ln_test & (int32_t)0xffff0000) != (int32_t)VITX_LN_TEST_KEY) { set_error("vitx_ctx_create_ex: ln_test is a test-only switch (it needs its key: include/vitx.h)"); return VITX_ERR_ARG; }
         c->ln_test = opt.ln_test & 0xffff;
         if (c->ln_test == 3) c->ln_timeout = 5000;       // real time-outs in the test: 50 us
     }
