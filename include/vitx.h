@@ -221,6 +221,10 @@ typedef struct vitx_prof_entry {
 int vitx_probe_mfma(int device, int dtype, int fill, double target_ms, double *tflops, double *clock_mhz);
 int vitx_profile_enable(vitx_ctx *c, int on);
 int vitx_profile_read(vitx_ctx *c, vitx_prof_entry *out, int max_entries, int *n_entries);
+/* What one HIP-event bracket adds to a launch's duration, in microseconds (median of 32 brackets around a 20 us kernel that stamps its own
+ * duration, queued back to back on the context's stream): vitx_profile_read() reports RAW event intervals; a caller that wants device-side
+ * kernel durations subtracts launches x this (bench.py does, and says so in its line). */
+int vitx_profile_bracket_us(vitx_ctx *c, double *bracket_us);
 
 /* ---- single-kernel entry points (device pointers; used by the parity tests) - */
 /* y[M][N] (dtype) = LayerNorm(x[M][D] f32) * w + b, eps inside the sqrt (vit.cpp:808-812). */

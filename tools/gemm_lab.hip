@@ -46,9 +46,15 @@ template <typename T> __global__ void gather_kernel(const void *out, int epi, in
     got[s] = (epi == EPI_BIAS || epi == EPI_BIAS_GELU) ? (float)((const T *)out)[idx] : ((const float *)out)[idx];
 }
 
+// whole-buffer comparison of two launches' outputs (the woven build against the serial-epilogue build: the same bits are required)
+__global__ void diff_kernel(const uint32_t *a, const uint32_t *b, size_t n, unsigned long long *cnt, unsigned long long *first) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (a[i] != b[i]) { atomicAdd(cnt, 1ull); atomicMin(first, (unsigned long long)i); }
+}
+
 static double gelu_ref(double x) { return 0.5 * x * (1.0 + tanh(0.79788456080286535588 * x * (1.0 + 0.044715 * x * x))); }
 
-struct Shape { const char *name; int M, N, K; };
+struct Shape { const char *name; int M, N, K; int Mr = 0; };   // Mr: rows stored (0 = all M): the last row block is then an edge tile
 struct Variant { const char *name; int kind; int cfg; };   // kind 0: ring cfg, 1: ping-pong
 
 template <typename T>
@@ -63,11 +69,12 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
     fill_f32<<<64, 256>>>(bias, (size_t)N, 3u, 0.5f);
     fill_f32<<<2048, 256>>>((float *)out, (size_t)M * N * out_elem / 4, 4u, epi == EPI_BIAS_RESID ? 1.0f : 0.0f);
     CK(hipDeviceSynchronize());
-    g.A = A; g.W = W; g.bias = bias; g.out = out; g.pos = nullptr; g.M = M; g.M_real = M; g.N = N; g.N_pad = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = 0;
+    g.A = A; g.W = W; g.bias = bias; g.out = out; g.pos = nullptr; g.M = M; g.M_real = sh.Mr > 0 ? sh.Mr : M; g.N = N; g.N_pad = N; g.K = K; g.lda = K; g.ldw = K; g.ldo = N; g.tpi = 0;
     if (const char *e = getenv("LAB_GROUP_M")) g.group_m = atoi(e);
     unsigned *tl = nullptr;
     if (v.kind == 1 && (v.cfg & 32)) { CK(hipMalloc(&tl, 256 * 8 * 64 * 4)); CK(hipMemset(tl, 0, 256 * 8 * 64 * 4)); g.pos = (const float *)tl; }
-    if (v.kind == 1 && (v.cfg & (28 | 2048))) check = false;      // ablation builds compute garbage on purpose
+    if (v.kind == 1 && (v.cfg & (28 | 2048))) check = false;
+    if (v.kind == 1 && (v.cfg & 12288)) check = true;      // ablation builds compute garbage on purpose
     const bool brief = false;
     auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(*g_tune, dtype, epi, g, v.cfg, 0) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
 
@@ -77,8 +84,10 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
         const int S = 4096;
         std::vector<int> sm(S), sn(S);
         uint32_t r = 12345u;
-        for (int s = 0; s < S; ++s) { r = r * 1664525u + 1013904223u; sm[s] = (r >> 8) % M; r = r * 1664525u + 1013904223u; sn[s] = (r >> 8) % N; }
-        sm[0] = 0; sn[0] = 0; sm[1] = M - 1; sn[1] = N - 1; sm[2] = 0; sn[2] = N - 1; sm[3] = M - 1; sn[3] = 0; sm[4] = 255; sn[4] = 255; sm[5] = 128; sn[5] = 64;
+        const int Mr = g.M_real, npad = Mr < M ? 256 : 0;        // the last `npad` samples probe the pad rows Mr .. M: they must keep their fill (0)
+        for (int s = 0; s < S; ++s) { r = r * 1664525u + 1013904223u; sm[s] = (r >> 8) % Mr; r = r * 1664525u + 1013904223u; sn[s] = (r >> 8) % N; }
+        sm[0] = 0; sn[0] = 0; sm[1] = Mr - 1; sn[1] = N - 1; sm[2] = 0; sn[2] = N - 1; sm[3] = Mr - 1; sn[3] = 0; sm[4] = 255; sn[4] = 255; sm[5] = 128; sn[5] = 64;
+        for (int s = S - npad; s < S; ++s) sm[s] = Mr + (s * 7) % (M - Mr);
         int *dsm, *dsn; double *dref; float *dgot, *dprev;
         CK(hipMalloc(&dsm, S * 4)); CK(hipMalloc(&dsn, S * 4)); CK(hipMalloc(&dref, S * 8)); CK(hipMalloc(&dgot, S * 4)); CK(hipMalloc(&dprev, S * 4));
         CK(hipMemcpy(dsm, sm.data(), S * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dsn, sn.data(), S * 4, hipMemcpyHostToDevice));
@@ -99,6 +108,7 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
                 if (epi == EPI_BIAS) tol += ulp * fabs(want);
                 if (epi == EPI_BIAS_GELU) { want = gelu_ref(want); tol = 2.5 * ulp * (fabs(want) + 0.02) + 3e-3 * ulp * 128; }
                 if (epi == EPI_BIAS_RESID) want += (double)prev[s];
+                if (s >= S - npad) { want = (double)prev[s]; tol = 0.0; if ((double)got[s] == want) continue; }
                 const double err = fabs((double)got[s] - want) / tol;
                 if (!(err <= 1.0)) { if (bad < 16 && getenv("LAB_SHOWBAD")) printf("   bad: m %d (%d) n %d (%d) got %g want %g\n", sm[s], sm[s] % 256, sn[s], sn[s] % 256, got[s], want); ++bad; }
                 if (!(err <= worst)) worst = err;
@@ -123,9 +133,22 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
         CK(hipEventRecord(e0, 0)); (void)launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
     }
+    char same[96] = "";
+    if (v.kind == 1 && v.cfg == 0 && out_elem == 2) {      // the output the back-to-back launches left, bit for bit against the serial-epilogue build
+        void *out2; unsigned long long *cnt, h[2] = {0, ~0ull};
+        CK(hipMalloc(&out2, (size_t)M * N * 2)); CK(hipMemset(out2, 0, (size_t)M * N * 2)); CK(hipMalloc(&cnt, 16)); CK(hipMemcpy(cnt, h, 16, hipMemcpyHostToDevice));
+        GemmArgs g2 = g; g2.out = out2;
+        hipError_t le = launch_gemm_pp(dtype, epi, g2, n_cu, 0, 64);
+        diff_kernel<<<2048, 256>>>((const uint32_t *)out, (const uint32_t *)out2, (size_t)M * N / 2, cnt, cnt + 1);
+        CK(hipDeviceSynchronize()); CK(hipMemcpy(h, cnt, 16, hipMemcpyDeviceToHost));
+        if (le != hipSuccess) snprintf(same, sizeof same, "  [serial build: launch failed]");
+        else if (h[0]) snprintf(same, sizeof same, "  [!= serial build: %llu words, first at row %llu col %llu]", h[0], h[1] * 2 / N, h[1] * 2 % N);
+        else snprintf(same, sizeof same, "  [== serial build]");
+        CK(hipFree(out2)); CK(hipFree(cnt));
+    }
     const double us = total / iters * 1e3, tf = 2.0 * M * N * (double)K / (total / iters) / 1e9;
-    printf("%-7s M=%-6d N=%-5d K=%-5d %-8s epi=%d %s  mean %9.1f us  best %9.1f us  %7.1f TF/s  %s\n", sh.name, M, N, K, v.name, epi, dtype == DT_F16 ? "f16 " : "bf16",
-           us, best * 1e3, tf, verdict);
+    printf("%-7s M=%-6d N=%-5d K=%-5d %-9s epi=%d %s  mean %9.1f us  best %9.1f us  %7.1f TF/s  %s%s\n", sh.name, M, N, K, v.name, epi, dtype == DT_F16 ? "f16 " : "bf16",
+           us, best * 1e3, tf, verdict, same);
     fflush(stdout);
     if (tl) {      // timeline: stamps after each barrier (2 per phase, 16 phases = K-tiles 4..7 of the first tile), waves 0 and 4 of a few workgroups
         std::vector<unsigned> h(256 * 8 * 64);
@@ -133,8 +156,8 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
         for (int b : {0, 1, 100, 255}) for (int w : {0, 4}) {
             const unsigned *st = &h[((size_t)b * 8 + w) * 64];
             printf("   timeline block %3d wave %d: deltas:", b, w);
-            const int ns = (v.cfg & 64) ? 60 : 32;
-            for (int i = 1; i < ns; ++i) printf((v.cfg & 64) && i % 5 == 0 ? " %u |" : " %u", st[i] - st[i - 1]);
+            const int ns = (v.cfg & 128) ? 64 : 32;          // two stamps per phase, eight per K-tile
+            for (int i = 1; i < ns; ++i) printf(i % 8 == 0 ? " | %u" : " %u", st[i] - st[i - 1]);
             printf("\n");
         }
         if (v.cfg & 1024) {     // arrival stamps: per barrier, arrival of the first-row wave 0 and of the second-row wave 4 (which is one barrier behind)
@@ -168,28 +191,33 @@ int main(int argc, char **argv) {
     const Shape shapes[] = {
         {"tiny", 512, 512, 256}, {"edge", 768, 1024, 384}, {"sq4k", 4096, 4096, 4096}, {"sq8k", 8192, 8192, 8192},
         {"qkv", 50432, 2304, 768}, {"proj", 50432, 768, 768}, {"fc1", 50432, 3072, 768}, {"fc2", 50432, 768, 3072},
+        {"hqkv", 25344, 2304, 768, 25216}, {"hfc1", 25344, 3072, 768, 25216},      // an average sub-batch of the forward (128 images; the last row block is an edge tile)
+        {"ragged", 1280, 768, 512, 1100}, {"k256", 1024, 512, 256}, {"k128", 512, 512, 128},
         {"qkvL", 73984, 3072, 1024}, {"fc2L", 73984, 1024, 4096},
     };
     // kind 1 = ping-pong kernel, cfg = its FLAGS (gemm_pp.hip; non-zero builds exist under -DVITX_LAB only, which this tool is compiled with)
-    const Variant variants[] = {{"ring945", 0, 945}, {"pp", 1, 0}, {"pp_noprio", 1, 1}, {"pp_nodma", 1, 4}, {"pp_noread", 1, 8}, {"pp_mfmaonly", 1, 12},
+    const Variant variants[] = {{"ring945", 0, 945}, {"pp", 1, 0}, {"pp_serial", 1, 64}, {"pp_wstamp", 1, 160}, {"pp_sstamp", 1, 224}, {"pp_fill2", 1, 4160}, {"pp_fill3", 1, 8256}, {"pp_fill4", 1, 12352}, {"pp_noprio", 1, 1}, {"pp_nodma", 1, 4}, {"pp_noread", 1, 8}, {"pp_mfmaonly", 1, 12},
                                 {"pp_nomfma", 1, 16}, {"pp_stamp", 1, 32}, {"pp_drain", 1, 512}, {"pp_noepi", 1, 2048}};
     for (const Shape &sh : shapes)
         for (const Variant &v : variants) {
             int epis[4] = {EPI_BIAS, -1, -1, -1};
             if (!strcmp(sh.name, "proj") || !strncmp(sh.name, "fc2", 3)) epis[0] = EPI_BIAS_RESID;
-            if (!strcmp(sh.name, "fc1")) epis[0] = EPI_BIAS_GELU;
+            if (!strcmp(sh.name, "fc1") || !strcmp(sh.name, "hfc1")) epis[0] = EPI_BIAS_GELU;
             if (!strcmp(sh.name, "tiny") || !strcmp(sh.name, "edge")) { epis[1] = EPI_BIAS_GELU; epis[2] = EPI_BIAS_RESID; epis[3] = EPI_BIAS_F32; }
+            if (!strcmp(sh.name, "ragged") || !strcmp(sh.name, "k256") || !strcmp(sh.name, "k128")) epis[1] = EPI_BIAS_GELU;
             for (int e = 0; e < 4; ++e) {
-                if (epis[e] < 0 || (v.kind == 1 && v.cfg && epis[e] != EPI_BIAS)) continue;
+                if (epis[e] < 0 || (v.kind == 1 && v.cfg && v.cfg != 64 && epis[e] != EPI_BIAS)) continue;
+                if (v.kind == 1 && v.cfg == 64 && epis[e] != EPI_BIAS && epis[e] != EPI_BIAS_GELU) continue;
+                if (v.kind == 0 && sh.Mr) continue;
                 for (int dtype = 0; dtype < 2; ++dtype) {
-                    if (dtype == 0 && strcmp(sh.name, "tiny") && strcmp(sh.name, "edge") && strcmp(sh.name, "qkv")) continue;    // f16: correctness shapes + one big one
+                    if (dtype == 0 && strcmp(sh.name, "tiny") && strcmp(sh.name, "edge") && strcmp(sh.name, "qkv") && strcmp(sh.name, "ragged") && strcmp(sh.name, "k256")) continue;    // f16: correctness shapes + one big one
                     char tag[96]; snprintf(tag, sizeof tag, "%s:%s:%d:%s", sh.name, v.name, epis[e], dtype ? "bf16" : "f16");
                     if (filter[0]) {       // comma-separated substrings: any match runs the case
                         bool hit = false; std::string f(filter); size_t pos = 0;
                         while (pos <= f.size()) { size_t c = f.find(',', pos); if (c == std::string::npos) c = f.size(); if (c > pos && strstr(tag, f.substr(pos, c - pos).c_str())) hit = true; pos = c + 1; }
                         if (!hit) continue;
                     }
-                    const bool small = sh.M <= 1024;
+                    const bool small = sh.M <= 1280;
                     if (dtype == DT_F16) run_one<_Float16>(sh, v, epis[e], dtype, small ? 3 : iters, n_cu, true);
                     else run_one<__bf16>(sh, v, epis[e], dtype, small ? 3 : iters, n_cu, true);
                 }

@@ -28,7 +28,7 @@ EXPORTS = [
     "vitx_status_str", "vitx_last_error", "vitx_model_load", "vitx_model_free", "vitx_model_uid", "vitx_model_hparams", "vitx_model_num_labels",
     "vitx_model_label", "vitx_model_num_tensors", "vitx_model_tensor_info", "vitx_model_tensor_f32", "vitx_quantize_file", "vitx_image_load", "vitx_image_decode", "vitx_image_free", "vitx_preprocess_u8", "vitx_preprocess_u8_device",
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
-    "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
+    "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_profile_bracket_us", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_ctx_shares_weights", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
     "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_ctx_ln_fusion_active", "vitx_op_attention_f32", "vitx_op_attention_planes", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
@@ -103,6 +103,7 @@ def lib():
         L.vitx_topk.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.vitx_profile_enable.argtypes = [vp, ip]
         L.vitx_profile_read.argtypes = [vp, C.POINTER(ProfEntry), ip, C.POINTER(ip)]
+        L.vitx_profile_bracket_us.argtypes = [vp, C.POINTER(C.c_double)]
         L.vitx_op_layernorm.argtypes = [ip, vp, vp, vp, vp, ip, ip, C.c_float, vp]
         L.vitx_op_gemm.argtypes = [ip, ip, vp, vp, vp, vp, ip, ip, ip, vp]
         L.vitx_op_attention.argtypes = [ip, vp, vp, ip, ip, ip, ip, vp]
@@ -340,6 +341,12 @@ class Context:
 
     def profile_enable(self, on: bool = True) -> None:
         check(lib().vitx_profile_enable(self._h, int(on)))
+
+    def profile_bracket_us(self) -> float:
+        """Microseconds one HIP-event bracket adds to a launch (vitx_profile_bracket_us); profile_read() intervals are raw."""
+        v = C.c_double()
+        check(lib().vitx_profile_bracket_us(self._h, C.byref(v)), "vitx_profile_bracket_us")
+        return float(v.value)
 
     def profile_read(self):
         arr = (ProfEntry * 16)(); n = C.c_int()

@@ -938,6 +938,41 @@ int vitx_profile_enable(vitx_ctx *c, int on) {
     return VITX_OK;
 }
 
+// What the HIP-event bracket of vitx_profile_enable adds to ONE launch: 32 x [record, 20 us kernel that stamps its own first and last
+// wall-clock reading, record] queued back to back on the context's stream like a profiled forward; the median of
+// (event interval - the kernel's own interval).  bench.py subtracts it from every launch of the profiled step (r04: the bracket read
+// 5.3-5.5 us above the device's dispatch stamps for every kernel class, so `roofline.achieved` was 4-13 % low).
+int vitx_profile_bracket_us(vitx_ctx *c, double *bracket_us) {
+    if (!c || !bracket_us) return VITX_ERR_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    constexpr int NB = 32;
+    long long *d_st = nullptr; hipEvent_t ev[2 * NB];
+    HIP_TRY(hipMalloc((void **)&d_st, sizeof(long long) * 2 * NB));
+    int made = 0; hipError_t e = hipSuccess;
+    for (; made < 2 * NB && e == hipSuccess; ++made) e = hipEventCreate(&ev[made]);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    for (int i = 0; i < NB && e == hipSuccess; ++i) {
+        e = hipEventRecord(ev[2 * i], c->stream);
+        if (e == hipSuccess) e = launch_spin_stamp(20, d_st + 2 * i, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev[2 * i + 1], c->stream);
+    }
+    long long h_st[2 * NB];
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost);
+    std::vector<double> over;
+    for (int i = 0; i < NB && e == hipSuccess; ++i) {
+        float ms = 0.0f;
+        e = hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        over.push_back((double)ms * 1e3 - (double)(h_st[2 * i + 1] - h_st[2 * i]) * 0.01);
+    }
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    (void)hipFree(d_st);
+    if (e != hipSuccess) { set_error("vitx_profile_bracket_us: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    std::sort(over.begin(), over.end());
+    *bracket_us = over[over.size() / 2];
+    return VITX_OK;
+}
+
 int vitx_profile_read(vitx_ctx *c, vitx_prof_entry *out, int max_entries, int *n_entries) {
     if (!c || !out || !n_entries) return VITX_ERR_ARG;
     HIP_TRY(hipSetDevice(c->device));

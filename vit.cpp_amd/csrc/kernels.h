@@ -145,6 +145,8 @@ hipError_t launch_preprocess(const void *u8, float *out, int n, int nx, int ny, 
 hipError_t launch_topk(const float *probs, int rows, int cols, int k, void *out_pairs, hipStream_t stream);
 // one workgroup that does nothing for `microseconds` of the 100 MHz wall clock (stream-concurrency probe of the execution context)
 hipError_t launch_spin(int microseconds, hipStream_t stream);
+// the same, writing its first and last wall-clock reading (100 MHz ticks) to stamps[0..1] (device memory)
+hipError_t launch_spin_stamp(int microseconds, long long *stamps, hipStream_t stream);
 
 
 // internal: kernel families.  `prepare` = only set the dynamic-LDS attribute of the instantiation (device bring-up).

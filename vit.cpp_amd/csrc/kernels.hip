@@ -1440,6 +1440,18 @@ hipError_t launch_spin(int microseconds, hipStream_t stream) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, (long long)microseconds * 100);
     return hipGetLastError();
 }
+// the same, leaving its own first and last reading of the 100 MHz wall clock in stamps[0..1]: a kernel whose duration the device itself
+// states, the yardstick for what a HIP-event bracket adds to a launch (vitx_profile_bracket_us)
+__global__ void spin_stamp_kernel(long long ticks, long long *stamps) {
+    const long long t0 = wall_clock64();
+    long long t1 = t0;
+    while (t1 - t0 < ticks) { __builtin_amdgcn_s_sleep(2); t1 = wall_clock64(); }
+    if (threadIdx.x == 0) { stamps[0] = t0; stamps[1] = t1; }
+}
+hipError_t launch_spin_stamp(int microseconds, long long *stamps, hipStream_t stream) {
+    hipLaunchKernelGGL(spin_stamp_kernel, dim3(1), dim3(64), 0, stream, (long long)microseconds * 100, stamps);
+    return hipGetLastError();
+}
 hipError_t launch_topk(const float *probs, int rows, int cols, int k, void *out_pairs, hipStream_t stream) {
     if (rows <= 0 || cols <= 0 || k <= 0 || k > cols) return hipErrorInvalidValue;
     hipLaunchKernelGGL(topk_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, probs, rows, cols, k, (float *)out_pairs);
