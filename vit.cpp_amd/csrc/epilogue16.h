@@ -11,8 +11,6 @@
 // residual add in f32 (:868-873, :899-902); EPI_BIAS_F32 classifier head (:917-922); EPI_PATCH patch embedding + position
 // embedding, patch row -> token row (:774-800).
 #pragma once
-#include <type_traits>
-
 #include "device_common.h"
 #include "kernels.h"
 
@@ -218,79 +216,6 @@ __device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const
                 if constexpr (EPI == EPI_BIAS_RESID) d[t] = d[t] + __builtin_bit_cast(f32x4, res[c & 1][t]);     // (acc + bias) + x, the reference's order (vit.cpp:868-873)
                 pp_store_b128<AUX>(__builtin_bit_cast(u32x4, d[t]), ro, voff + j * 128, soff + (b * 2 + t) * soff8);
             }
-        }
-    }
-}
-
-// ---- woven epilogue of the ping-pong kernel (r05; 16-bit-output kinds): the epilogue as a list of single-instruction STEPS that the kernel
-// issues in the gaps behind the MFMAs of its K loop (gemm_pp.hip "WOVEN EPILOGUE").  A UNIT is 16 rows x 32 columns of the wave's block:
-// accumulator tiles (b, 2 hb) and (b, 2 hb + 1).  No LDS staging: after the bias add and the rounding a lane holds columns 4 g4 .. 4 g4 + 3 of
-// both 16-column tiles as two packed registers each; two v_permlane16_swap exchange the odd 16-lane rows of the first tile's registers with
-// the even rows of the second's, which leaves every lane with 8 CONSECUTIVE columns of its row:
-//     g4 = 0: tile 0, columns 0..7     g4 = 1: tile 1, columns 0..7     g4 = 2: tile 0, columns 8..15     g4 = 3: tile 1, columns 8..15
-// so one buffer_store_dwordx4 writes 16 rows x 64 contiguous bytes (lane's column offset {0, 16, 8, 24}[g4] of the unit's 32).
-// The bias is four registers, H[u] = bias[16 u + 4 g4 + (l15 & 3)], and reaches the add through the DPP operand (row_newbcast: e gives every
-// lane of a 16-lane row the value of the row's lane e = column 16 u + 4 g4 + e): the same v + bias in f32, the same bits as epilogue16_staged.
-template <int E> __device__ __forceinline__ float add_bias_dpp(float x, float h) {
-    float r;
-    if constexpr (E == 0) asm("v_add_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(h), "v"(x));
-    if constexpr (E == 1) asm("v_add_f32_dpp %0, %1, %2 row_newbcast:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(h), "v"(x));
-    if constexpr (E == 2) asm("v_add_f32_dpp %0, %1, %2 row_newbcast:2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(h), "v"(x));
-    if constexpr (E == 3) asm("v_add_f32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(h), "v"(x));
-    return r;
-}
-struct WvRegs { float v[8]; unsigned p[4]; };       // a unit's values in flight: the eight biased sums, then the four packed pairs
-// steps of one unit: 0..7 bias adds, 8..11 activation + rounding of a pair, 12..13 (HILO: + 14..17 lo plane, 18..19) lane exchange, then one
-// store per plane; wv_weight = issue slots of a step (quarter-rate transcendentals count four), what the kernel balances the gaps with
-template <int EPI> __host__ __device__ constexpr int wv_steps() { return EPI == EPI_BIAS_HILO ? 22 : 15; }
-template <typename T, int EPI> __host__ __device__ constexpr int wv_weight(int s) {
-    if (s < 8) return 1;
-    if (s < 12) return EPI == EPI_BIAS_GELU ? (std::is_same<T, _Float16>::value ? 24 : 22) : 1;
-    if constexpr (EPI == EPI_BIAS_HILO) { if (s >= 15 && s < 19) return 3; if (s == 14 || s == 21) return 2; return 1; }
-    return s == 14 ? 2 : 1;
-}
-// acc: the wave's accumulators; B, HB: the unit; S: the step.  voff = lane's byte offset (row l15, wave column block, {0, 16, 8, 24}[g4] columns),
-// soff = byte offset of row 0 of the wave's block in the tile being stored, soff16 = 16 rows, hilo_soff = byte distance of the lo plane.
-template <typename T, int EPI, int B, int HB, int S>
-__device__ __forceinline__ void wv_step(f32x4 (&acc)[8][4], const float (&H)[4], WvRegs &r, u32x4 &d2, __amdgpu_buffer_rsrc_t ro, int voff, int soff, int soff16, int hilo_soff) {
-    typedef typename Pair<T>::v2 v2;
-    if constexpr (S < 8) {
-        constexpr int u = 2 * HB + (S >> 2), e = S & 3;
-        r.v[S] = add_bias_dpp<e>(acc[B][u][e], H[u]);
-    } else if constexpr (S < 12) {
-        constexpr int j = S - 8;
-        v2 p;
-        if constexpr (EPI == EPI_BIAS_GELU) p = gelu_out_pair<T>(r.v[2 * j], r.v[2 * j + 1]);
-        else p = round_pair<T>(r.v[2 * j], r.v[2 * j + 1]);
-        r.p[j] = __builtin_bit_cast(unsigned, p);
-    } else if constexpr (EPI != EPI_BIAS_HILO) {
-        if constexpr (S < 14) {       // p[0], p[1] = tile 0 (columns 0..1, 2..3 of the lane's four); p[2], p[3] = tile 1
-            constexpr int k = S - 12;
-            const auto x = __builtin_amdgcn_permlane16_swap(r.p[k], r.p[2 + k], false, false);
-            const unsigned x0 = x[0], x1 = x[1];
-            r.p[k] = x0; r.p[2 + k] = x1;
-        } else {
-            pp_store_b128(u32x4{r.p[0], r.p[1], r.p[2], r.p[3]}, ro, voff + HB * 64, soff + B * soff16);
-        }
-    } else {       // two planes: hi as above; lo = round((v - hi) * 2048) of the same eight sums
-        if constexpr (S == 12 || S == 13) {      // hi plane into d2 (r.p keeps the un-swapped hi pairs for the lo plane)
-            constexpr int k = S - 12;
-            const auto x = __builtin_amdgcn_permlane16_swap(r.p[k], r.p[2 + k], false, false);
-            const unsigned x0 = x[0], x1 = x[1];
-            d2[k] = x0; d2[2 + k] = x1;
-        } else if constexpr (S == 14) {
-            pp_store_b128(d2, ro, voff + HB * 64, soff + B * soff16);
-        } else if constexpr (S < 19) {
-            constexpr int j = S - 15;
-            const v2 hi = __builtin_bit_cast(v2, r.p[j]);
-            r.p[j] = __builtin_bit_cast(unsigned, hilo_lo_pair<T>(r.v[2 * j], r.v[2 * j + 1], hi));
-        } else if constexpr (S < 21) {
-            constexpr int k = S - 19;
-            const auto x = __builtin_amdgcn_permlane16_swap(r.p[k], r.p[2 + k], false, false);
-            const unsigned x0 = x[0], x1 = x[1];
-            r.p[k] = x0; r.p[2 + k] = x1;
-        } else {
-            pp_store_b128(u32x4{r.p[0], r.p[1], r.p[2], r.p[3]}, ro, voff + HB * 64, soff + B * soff16 + hilo_soff);
         }
     }
 }

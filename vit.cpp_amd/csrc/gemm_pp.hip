@@ -283,25 +283,8 @@ __device__ __forceinline__ bool pp_epilogue_ln(const GemmArgs &g, const GemmLn &
 
 // FLAGS: 0 in the product.  Ablation builds exist only under -DVITX_LAB (tools/gemm_lab): 1 = no s_setprio around the MFMAs,
 // 4 = no LDS-DMA in the loop, 8 = no fragment reads, 16 = no MFMAs, 32 = s_memtime stamp after every barrier of K-tiles 4..7 of the first
-// tile (written to g.pos as [block][wave][64] u32; + 128: of the last four K-tiles of the first tile and the first four of the second),
-// 64 = the 16-bit-output epilogues run behind the K loop as in r01-r04 instead of woven into it, 512 = direct (unstaged) epilogue,
-// 2048 = no epilogue at all.
+// tile (written to g.pos as [block][wave][64] u32), 512 = direct (unstaged) epilogue, 2048 = no epilogue at all.
 // LNF: EPI_BIAS_RESID with the LayerNorm of the output rows computed in the epilogue (GemmLn, kernels.h; pp_epilogue_ln below).
-//
-// WOVEN EPILOGUE (r05; EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_HILO: the qkv and fc1 launches, 45 % of the forward's kernel time).  r01-r04 ran a
-// tile's epilogue behind its K loop with the matrix pipe idle (16 % of a qkv tile, 30 % of an fc1 tile).  The snake order leaves every
-// accumulator quadrant idle for three phases around the tile boundary -- C00 / C01 (the wave's rows 0..63) are final after phases 1 / 2 of the
-// LAST K-tile and not touched again before phases 1 / 2 of the next tile's first K-tile; C11 / C10 (rows 64..127) are final after phases
-// 3 / 4 and free until phases 3 / 4 of the next tile.  So the staged epilogue is cut into four pieces of two 16-row blocks each and issued in
-// the LOAD half of four phases -- where a wave otherwise waits at the barrier for its partner row's MFMAs:
-//     last K-tile  phase 3: blocks 0, 1     phase 4: blocks 2, 3          (rows 0..63 of the wave)
-//     next K-tile  phase 1: blocks 4, 5     phase 2: blocks 6, 7          (rows 64..127; the accumulators of C00 / C01 are re-zeroed beside them)
-// No second accumulator set, no extra LDS, no alignment of the wave rows around an epilogue.  The stores (4 per piece, 8 for HILO) join
-// the operand stream's counted vmcnt: every wait of the nine phases behind a piece names exactly the operations younger than the stage it
-// retires (table at PP_WV_WAIT).  The bias of a tile is DMA'd into the wave's patch in phase 3 of its first K-tile (after the previous
-// tile's last staging pass) and taken into four registers before the first piece overwrites it (epilogue16_woven_pair).
-// A tile that is not full (row / column edge) keeps the direct epilogue behind its K loop; the pieces of a workgroup's last tile that have
-// no next K-tile to ride on run after the loop.
 template <typename T, int EPI, int FLAGS, bool LNF = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR))) void gemm_pp_kernel(GemmArgs g, GemmLn ln) {
     using namespace pp;
@@ -311,9 +294,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;            // wave row (= ping-pong group) / wave column
-    // woven epilogue (see above): the 16-bit-output kinds of the full-featured build
-    constexpr bool WV = !LNF && (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_HILO) && !(FLAGS & (64 | 512 | 2048));
-    constexpr int WS = EPI == EPI_BIAS_HILO ? 8 : 4;    // stores of one woven piece
 
     // ---- tile walk: virtual id v keeps v % 8 == bid % 8 (same XCD), then the XCD-contiguous GROUP_M raster.
     // LNF: an XCD owns whole ROW BLOCKS and walks them column-fastest, and the launcher makes the workgroups per XCD a multiple of
@@ -445,23 +425,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             for (int k2 = 0; k2 < 2; ++k2) fb[h][u * 2 + k2] = *(const v8 *)(smem + off_b(buf, h) + rdB16[u][k2]);
     };
     // one C quadrant: 16 MFMAs of 16 cycles; k-step major, 8 independent accumulators in between
-    float probe_d[4] = {1.0f, 2.0f, 3.0f, 4.0f};    // FLAGS 4096 / 8192 (lab): 2 / 3 / 4 independent VALU instructions behind every MFMA -- what a gap holds for free
     auto mma = [&](int ha, int hb) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 2; ++u)
                     acc16[ha * 4 + t][hb * 2 + u] = Elem<T>::mfma16(fb[hb][u * 2 + k2], fa[t >> 1][(t & 1) * 2 + k2], acc16[ha * 4 + t][hb * 2 + u]);
-                    if constexpr ((FLAGS & (4096 | 8192)) != 0) {
-                        constexpr int NF = (FLAGS & 4096 ? 2 : 0) + (FLAGS & 8192 ? 3 : 0) - ((FLAGS & 12288) == 12288 ? 1 : 0);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int f = 0; f < NF; ++f) asm volatile("v_add_f32 %0, %0, %0" : "+v"(probe_d[f]));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
     };
 
     unsigned stamps = 0; int n_stamp = -1;          // timeline experiment (FLAGS 32): lane i of `stamps` = i-th stamp
@@ -474,14 +445,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             }
         }
     };
-    // one phase = [reads, stage, (woven epilogue piece)] | counted wait | barrier | 16 MFMAs | barrier
-#define PP_PHASE(READS, PRE, STAGE, POST, WAIT, HA, HB)                                    \
+    // one phase = [reads, stage] | counted wait | barrier | 16 MFMAs | barrier
+#define PP_PHASE(READS, STAGE, VMCNT, HA, HB, FIRST, FIRST_STMT)                                              \
     {                                                                                      \
         if (!(FLAGS & 8)) { READS; }                                                       \
-        PRE;                                                                               \
+        if (FIRST) { FIRST_STMT; }                                                         \
         if (!(FLAGS & 4)) { STAGE; }                                                       \
-        POST;                                                                              \
-        WAIT;                                                                              \
+        if (FIRST) { if (relaxed) pp_wait_vmcnt<VMCNT + 1 + pp_epi_stores<EPI>()>(); else pp_wait_vmcnt<VMCNT + 1>(); }   \
+        else pp_wait_vmcnt<VMCNT>();                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         pp_barrier();                                                                      \
         stamp();                                                                           \
@@ -496,9 +467,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     }
     // The first K-tile of a tile (`first`) also (a) zeroes each accumulator quadrant in the load part of the phase that first uses
     // it (the wave is waiting for its partner there anyway), (b) DMA-loads the bias of the wave's 64 columns into its epilogue
-    // patch (one more vector-memory op, issued BEFORE the phase's stage so only the four waits behind it count it), and
-    // (c) serial epilogue builds: if a full-tile epilogue ran just before (`relaxed`), skips over exactly pp_epi_stores() stores in
-    // those waits: they are younger than the stages being retired, and draining them costs microseconds when every CU stores at once.
+    // patch (one more vector-memory op, issued BEFORE the phase's stage so only this K-tile's four waits count it), and
+    // (c) if a full-tile epilogue ran just before (`relaxed`), skips over exactly pp_epi_stores() stores in those waits: they are
+    // younger than the stages being retired, and draining them costs microseconds when every CU stores at once.
     bool relaxed = false;
     int bias_so = 0;                                 // byte offset of the consumer tile's bias columns
     __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)g.bias, 0, (int)0xffffffffu, 0x00020000);
@@ -509,58 +480,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             for (int u = 0; u < 2; ++u) acc16[ha * 4 + t][hb * 2 + u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     };
     auto stage_bias = [&]() { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, LPTR(smem + LDS + wave * 4096), 4, lane * 4, bias_so, 0, 0); };
-    // ---- woven epilogue state (WV builds).  Hb = the four bias registers of epilogue16_woven_pair, wv_soff / wv_row = where the tile
-    // whose pieces are in flight lives (its last two pieces are issued while the loop variables already describe the next tile).
-    float Hb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int wv_soff = 0;
-    const int wv_row = (wr * 128 * g.ldo + wc * 64) * 2, wv_soff8 = 8 * g.ldo * 2;
-    auto wv_begin = [&](int m0, int n0) {           // phase 3 of a woven tile's last K-tile, before its first piece: bias -> registers (the piece overwrites the patch)
-        int l = lane; asm volatile("" : "+v"(l));
-        const float *bp = (const float *)(smem + LDS + wave * 4096) + (l >> 4) * 4 + (l & 3);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) Hb[u] = bp[u * 16];
-        pp_lds_fence();
-        wv_soff = __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * 2);
-    };
-    auto wv_piece = [&](auto b0c) {                  // blocks b0, b0 + 1 of the wave
-        constexpr int B0 = decltype(b0c)::value;
-        int l = lane; asm volatile("" : "+v"(l));
-        epilogue16_woven_pair<T, EPI, B0>(acc16, Hb, rsrcO, smem + LDS + wave * 4096, wv_row + (l >> 3) * wv_soff8 / 8, wv_soff, wv_soff8, l, (int)(g.hilo_off * 2));
-    };
-    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4; typedef std::integral_constant<int, 6> I6;
-    // PP_WV_WAIT: vmcnt of a phase X = the vector-memory operations issued AFTER the stage it retires (the stage of phase X - 4: LEAD = 4 stages
-    // of STAGE_OPS = 2 stay in flight).  Per phase, in program order: [bias DMA] stage (2) [piece: WS stores].  With P = last K-tile of a woven
-    // tile, Q / R = first / second K-tile of the tile behind it, W8 = 8, S = WS:
-    //     P3 W8+S   P4 W8+2S   Q1 W8+3S   Q2 W8+4S   Q3 W8+4S+1 (bias)   Q4 W8+3S+1   R1 W8+2S+1   R2 W8+S+1   R3 W8
-    // and behind a tile that was not woven (first tile, edge tile: its direct epilogue's stores are simply waited for): Q1 Q2 W8, Q3 Q4 R1 R2 W8+1.
-#define PP_WAIT2(C, A, B) { if (C) pp_wait_vmcnt<(A)>(); else pp_wait_vmcnt<(B)>(); }
-    // ktile(buffer, first, after, last): `first` = K-tile 0 (buffer 0) or 1 (buffer 1) of a tile; WV: `after` = ... behind a woven tile,
-    // `last` = last K-tile of a woven tile (buffer 1; K >= 256 keeps it apart from K-tile 1)
-    auto ktile = [&](auto bc, bool first, bool after, bool last, int m0, int n0) {
+    auto ktile = [&](auto bc, bool first) {
         constexpr int B = decltype(bc)::value;       // buffer of the K-tile being consumed
         constexpr int W8 = LEAD * STAGE_OPS;
-        if constexpr (!WV) {
-            const bool f = B == 0 && first;
-#define PP_WAIT_SERIAL { if (f) { if (relaxed) pp_wait_vmcnt<W8 + 1 + pp_epi_stores<EPI>()>(); else pp_wait_vmcnt<W8 + 1>(); } else pp_wait_vmcnt<W8>(); }
-            PP_PHASE((read_a(B, 0), read_b(B, 0)), { if (f) { zero_quadrant(0, 0); stage_bias(); } }, stage_w(1, off_b(B ^ 1, 1)), (void)0, PP_WAIT_SERIAL, 0, 0)   // C00 ; B1 of the next K-tile
-            PP_PHASE(read_b(B, 1), { if (f) zero_quadrant(0, 1); }, (stage_a(1, off_a(B ^ 1, 1)), advance()), (void)0, PP_WAIT_SERIAL, 0, 1)                          // C01 ; A1 of the next K-tile
-            PP_PHASE(read_a(B, 1), { if (f) zero_quadrant(1, 1); }, stage_a(0, off_a(B, 0)), (void)0, PP_WAIT_SERIAL, 1, 1)                                       // C11 ; A0 two K-tiles ahead
-            PP_PHASE((void)0, { if (f) zero_quadrant(1, 0); }, stage_w(0, off_b(B, 0)), (void)0, PP_WAIT_SERIAL, 1, 0)                                            // C10 ; B0 two K-tiles ahead
-#undef PP_WAIT_SERIAL
-            if (f) relaxed = false;
-        } else if constexpr (B == 0) {               // Q: the previous tile's rows 64..127 leave in phases 1, 2; this tile's bias arrives in phase 3
-            PP_PHASE((read_a(B, 0), read_b(B, 0)), { if (first) zero_quadrant(0, 0); }, stage_w(1, off_b(B ^ 1, 1)), { if (after) wv_piece(I4{}); }, PP_WAIT2(after, W8 + 3 * WS, W8), 0, 0)
-            PP_PHASE(read_b(B, 1), { if (first) zero_quadrant(0, 1); }, (stage_a(1, off_a(B ^ 1, 1)), advance()), { if (after) wv_piece(I6{}); }, PP_WAIT2(after, W8 + 4 * WS, W8), 0, 1)
-            PP_PHASE(read_a(B, 1), { if (first) { zero_quadrant(1, 1); stage_bias(); } }, stage_a(0, off_a(B, 0)), (void)0, { if (after) pp_wait_vmcnt<W8 + 4 * WS + 1>(); else PP_WAIT2(first, W8 + 1, W8) }, 1, 1)
-            PP_PHASE((void)0, { if (first) zero_quadrant(1, 0); }, stage_w(0, off_b(B, 0)), (void)0, { if (after) pp_wait_vmcnt<W8 + 3 * WS + 1>(); else PP_WAIT2(first, W8 + 1, W8) }, 1, 0)
-        } else {                                     // R (first: K-tile 1) / P (last): rows 0..63 of this tile leave in phases 3, 4 of its last K-tile
-            PP_PHASE((read_a(B, 0), read_b(B, 0)), (void)0, stage_w(1, off_b(B ^ 1, 1)), (void)0, { if (after) pp_wait_vmcnt<W8 + 2 * WS + 1>(); else PP_WAIT2(first, W8 + 1, W8) }, 0, 0)
-            PP_PHASE(read_b(B, 1), (void)0, (stage_a(1, off_a(B ^ 1, 1)), advance()), (void)0, { if (after) pp_wait_vmcnt<W8 + WS + 1>(); else PP_WAIT2(first, W8 + 1, W8) }, 0, 1)
-            PP_PHASE(read_a(B, 1), (void)0, stage_a(0, off_a(B, 0)), { if (last) { wv_begin(m0, n0); wv_piece(I0{}); } }, PP_WAIT2(last, W8 + WS, W8), 1, 1)
-            PP_PHASE((void)0, (void)0, stage_w(0, off_b(B, 0)), { if (last) wv_piece(I2{}); }, PP_WAIT2(last, W8 + 2 * WS, W8), 1, 0)
-        }
+        const bool f = B == 0 && first;
+        PP_PHASE((read_a(B, 0), read_b(B, 0)), stage_w(1, off_b(B ^ 1, 1)), W8, 0, 0, f, (zero_quadrant(0, 0), stage_bias()))   // C00 ; B1 of the next K-tile
+        PP_PHASE(read_b(B, 1), (stage_a(1, off_a(B ^ 1, 1)), advance()), W8, 0, 1, f, zero_quadrant(0, 1))                        // C01 ; A1 of the next K-tile
+        PP_PHASE(read_a(B, 1), stage_a(0, off_a(B, 0)), W8, 1, 1, f, zero_quadrant(1, 1))                                     // C11 ; A0 two K-tiles ahead
+        PP_PHASE((void)0, stage_w(0, off_b(B, 0)), W8, 1, 0, f, zero_quadrant(1, 0))                                          // C10 ; B0 two K-tiles ahead
+        if (f) relaxed = false;
     };
+    typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 1> I1;
 
     // ---- prologue: A0 B0 B1 A1 of K-tile 0 and A0 B0 of K-tile 1 in flight, the first two landed
     stage_a(0, off_a(0, 0)); stage_w(0, off_b(0, 0)); stage_w(1, off_b(0, 1)); stage_a(1, off_a(0, 1)); advance();     // nkt >= 2: K-tile 1 exists
@@ -569,22 +499,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     pp_barrier();
     if (wr == 1) pp_barrier();                      // the second wave row runs one barrier behind the first
 
-    bool prev_wv = false;                           // WV: the previous tile's last two pieces are still to be issued
     for (int round = 0; round < my_tiles; ++round) {
         int m0, n0; tile_origin(round, m0, n0);
         bias_so = __builtin_amdgcn_readfirstlane((n0 + wc * 64) * 4);
-        const bool full = LNF || ((m0 + BM <= g.M_real) && (n0 + BN <= g.N));       // LNF: the padded rows are computed and stored too (GemmLn)
-        const bool cur_wv = WV && full && nkt >= 4;    // K = 128: K-tile 1 would also be the last one (the wait table keeps them apart)
         for (int kt = 0; kt < nkt; kt += 2) {
-            if constexpr ((FLAGS & 32) != 0) { if (round == 0 && kt == ((FLAGS & 128) ? nkt - 4 : 4)) n_stamp = 0; }
-            ktile(I0{}, kt == 0, kt == 0 && prev_wv, false, m0, n0); ktile(I1{}, kt == 0, kt == 0 && prev_wv, cur_wv && kt + 2 >= nkt, m0, n0);
+            if constexpr ((FLAGS & 32) != 0) { if (round == 0 && kt == 4) n_stamp = 0; }
+            ktile(I0{}, kt == 0); ktile(I1{}, false);
         }
-        prev_wv = cur_wv;
         if constexpr ((FLAGS & 8) != 0) {           // fragments never read: keep the MFMA operands "defined" for the compiler
             if (round == 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" : "+v"(fa[ii][ks])); asm volatile("" : "+v"(fb[ii][ks])); } }
         }
         if constexpr ((FLAGS & 16) != 0) { for (int ii = 0; ii < 2; ++ii) for (int ks = 0; ks < 4; ++ks) { asm volatile("" :: "v"(fa[ii][ks]), "v"(fb[ii][ks])); } }
-        if (cur_wv) continue;                       // its epilogue is in flight inside the K loop
+        const bool full = LNF || ((m0 + BM <= g.M_real) && (n0 + BN <= g.N));       // LNF: the padded rows are computed and stored too (GemmLn)
         // The second wave row runs one barrier behind, so its last K-loop barrier would only be released by the first row's first
         // barrier of the NEXT tile -- i.e. after the first row's epilogue, and the two rows' epilogues would run one after the other.
         // Aligning the rows here (and restoring the offset after the epilogue) lets both epilogues run at the same time: forward
@@ -593,7 +519,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         if constexpr ((FLAGS & 2048) != 0) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) asm volatile("" :: "v"(acc16[t][0]), "v"(acc16[t][1]), "v"(acc16[t][2]), "v"(acc16[t][3]));
-        } else if (!WV && full && EPI != EPI_PATCH && !(FLAGS & 512)) {
+        } else if (full && EPI != EPI_PATCH && !(FLAGS & 512)) {
             constexpr int esz = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_HILO) ? 2 : 4;
             // row layout of the stores: lane -> row (lane>>3) + 8t of a 32-row block, 16-byte piece lane&7 of the wave's 128-byte row segment
             const int voff = ((wr * 128 + (lane >> 3)) * g.ldo + wc * 64) * esz + (lane & 7) * 16;
@@ -611,20 +537,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             const int row0 = m0 + wr * 128 + l15, ncol = n0 + wc * 64;
             if (full) epilogue16<T, EPI, 8, 4, true>(g, acc16, row0, ncol + 4 * g4);
             else epilogue16<T, EPI, 8, 4, false>(g, acc16, row0, ncol + 4 * g4);
-            // WV: a drain the COMPILER can see (vmcnt(0), other counters untouched).  This epilogue's element-wise bias loads define registers
-            // under exec masks; left pending for hipcc's own wait insertion they reach the K loop's header around the back edge and cost a
-            // compiler-placed vmcnt(0) in front of the first fragment read of EVERY K-tile pair (the inline-asm waits are invisible to that pass).
-            if constexpr (WV) __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         if (wr == 1) pp_barrier();
     }
-    if constexpr (WV) { if (prev_wv) { wv_piece(I4{}); wv_piece(I6{}); } }      // the last tile's rows 64..127 have no next K-tile to ride on
     if (wr == 0) pp_barrier();
     pp_wait_vmcnt<0>();                             // the trailing (unused) stages must land before the LDS allocation is released
     if constexpr ((FLAGS & 32) != 0) ((unsigned *)g.pos)[((size_t)bid * 8 + wave) * 64 + lane] = stamps;
-    if constexpr ((FLAGS & (4096 | 8192)) != 0) { if (probe_d[0] + probe_d[1] + probe_d[2] + probe_d[3] == 12345.678f) ((float *)g.out)[0] = 0.0f; }
 #undef PP_PHASE
-#undef PP_WAIT2
 }
 
 bool gemm_pp_supports(const GemmArgs &a) {
@@ -671,22 +590,9 @@ static hipError_t launch_pp_ln(const GemmArgs &a, int n_cu, hipStream_t stream, 
 template <typename T>
 static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags, bool prepare) {
 #ifdef VITX_LAB
-    if (flags) {       // ablation builds (tools/gemm_lab) exist for the plain bias epilogue only (64: for every woven kind)
-        if (epi != EPI_BIAS && flags != 64) return hipErrorInvalidValue;
-        if (flags == 64) {      // the serial-epilogue build of the kinds the product weaves: the A/B partner of r05
-            switch (epi) {
-            case EPI_BIAS: return launch_pp_inst<T, EPI_BIAS, 64>(a, n_cu, stream, prepare);
-            case EPI_BIAS_GELU: return launch_pp_inst<T, EPI_BIAS_GELU, 64>(a, n_cu, stream, prepare);
-            case EPI_BIAS_HILO: return launch_pp_inst<T, EPI_BIAS_HILO, 64>(a, n_cu, stream, prepare);
-            default: return hipErrorInvalidValue;
-            }
-        }
+    if (flags) {       // ablation builds (tools/gemm_lab) exist for the plain bias epilogue only
+        if (epi != EPI_BIAS) return hipErrorInvalidValue;
         switch (flags) {
-        case 4160: return launch_pp_inst<T, EPI_BIAS, 4160>(a, n_cu, stream, prepare);
-        case 8256: return launch_pp_inst<T, EPI_BIAS, 8256>(a, n_cu, stream, prepare);
-        case 12352: return launch_pp_inst<T, EPI_BIAS, 12352>(a, n_cu, stream, prepare);
-        case 160: return launch_pp_inst<T, EPI_BIAS, 160>(a, n_cu, stream, prepare);
-        case 224: return launch_pp_inst<T, EPI_BIAS, 224>(a, n_cu, stream, prepare);
         case 1: return launch_pp_inst<T, EPI_BIAS, 1>(a, n_cu, stream, prepare);
         case 4: return launch_pp_inst<T, EPI_BIAS, 4>(a, n_cu, stream, prepare);
         case 8: return launch_pp_inst<T, EPI_BIAS, 8>(a, n_cu, stream, prepare);
