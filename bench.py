@@ -40,6 +40,7 @@ FTYPES = {"f16": 1, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}
 # unit roundoff 8 x fp16's): 2e-2, or ten times that noise -- the same ratio.  Both also need top-1 equal wherever the reference decides it.
 BOUND_BF16 = 2e-2
 BOUND_F16_FLOOR = 1e-3
+BOUND_Q_BF16 = 6e-3        # bf16 forward of a quantised file vs the bf16-rounding oracle on the same dequantised weights
 
 
 def committed_traffic():
@@ -145,23 +146,32 @@ class SmiSampler:
                 "series_t_W_MHz": [[t, round(w), round(m) if m else None] for t, w, m in self.samples]}
 
 
-def roofline_of(prof, prof_steps, traffic=None, traffic_src=None):
-    """Dominant GEMM class of one profiled step: algorithmic 2*M*N*K / HIP-event time on the launch stream; per-class table."""
+def roofline_of(prof, prof_steps, traffic=None, traffic_src=None, bracket_us=0.0):
+    """Dominant GEMM class of one profiled step: algorithmic 2*M*N*K / kernel time; per-class table.  Kernel time = the HIP-event interval
+    around each launch on the launch stream MINUS what the bracket itself adds (`bracket_us`, measured in this run by
+    vitx_profile_bracket_us: r04's line was 4-13 % low per class because the bracket reads ~5 us more than the device's dispatch stamps)."""
     gemms = [p for p in prof if p["name"].startswith("gemm_")]
     if not gemms:
         return None, None
-    dom = max(gemms, key=lambda p: p["busy_ms"])
-    tf = dom["flops"] / (dom["busy_ms"] * 1e-3) / 1e12
+    cal = lambda p: max(p["busy_ms"] - p["launches"] * bracket_us * 1e-3, 1e-6)       # sub-batches serialised: busy = sum of the launches' intervals
+    dom = max(gemms, key=cal)
+    tf = dom["flops"] / (cal(dom) * 1e-3) / 1e12
     roof = {"bound": "mfma", "kernel": dom["name"], "achieved": round(tf, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS, 4),
             "traffic": (traffic or {}).get(dom["name"]), "traffic_unit": "GB per launch", "traffic_source": traffic_src,
-            "avg_launch_ms": round(dom["total_ms"] / dom["launches"], 4), "flops_per_launch": dom["flops"] / dom["launches"],
+            "avg_launch_ms": round(cal(dom) / dom["launches"], 4), "avg_launch_ms_raw_event_interval": round(dom["total_ms"] / dom["launches"], 4),
+            "clock": f"HIP events on the launch stream around every launch, minus the measured cost of the bracket itself ({bracket_us:.2f} us per launch: "
+                     "median of 32 brackets around a 20 us kernel that stamps its own duration, queued back to back on the same stream -- vitx_profile_bracket_us)",
+            "bracket_us": round(bracket_us, 3),
+            "achieved_raw_event_interval": round(dom["flops"] / (dom["busy_ms"] * 1e-3) / 1e12, 1),
+            "flops_per_launch": dom["flops"] / dom["launches"],
             "launches_per_step": dom["launches"] / prof_steps,
             "measured_over": f"{prof_steps} profiled step(s) run right AFTER the timed steps, outside `value` (the timed steps all run the production schedule)",
             "schedule": "profiled step: sub-batches serialised on one stream (exclusive kernel durations); timed steps: 2 sub-batches on 2 HIP streams"}
-    tot = sum(p["busy_ms"] for p in prof)
-    table = {p["name"]: {"busy_ms_per_step": round(p["busy_ms"] / prof_steps, 4), "share": round(p["busy_ms"] / tot, 4), "launches": p["launches"] // prof_steps,
-                         "TFLOPs": round(p["flops"] / (p["busy_ms"] * 1e-3) / 1e12, 1) if p["flops"] else None,
-                         "GBps_algorithmic": round(p["bytes"] / (p["busy_ms"] * 1e-3) / 1e9, 1)} for p in prof}
+    tot = sum(cal(p) for p in prof)
+    table = {p["name"]: {"busy_ms_per_step": round(cal(p) / prof_steps, 4), "share": round(cal(p) / tot, 4), "launches": p["launches"] // prof_steps,
+                         "us_per_launch": round(cal(p) / p["launches"] * 1e3, 2),
+                         "TFLOPs": round(p["flops"] / (cal(p) * 1e-3) / 1e12, 1) if p["flops"] else None,
+                         "GBps_algorithmic": round(p["bytes"] / (cal(p) * 1e-3) / 1e9, 1)} for p in prof}
     return roof, table
 
 
@@ -177,9 +187,24 @@ def parity_rows(ctx, n, want):
     return sorted(ids)
 
 
-def parity_of(np, got, ref_p, bound, extra=None):
+def parity_of(np, got, ref_p, bound, extra=None, gate=None):
     """|dp| of `got` vs the reference-semantics probabilities on the same rows + the gate: max|dp| <= bound and top-1 equal wherever
-    the reference separates its two best classes by more than twice the measured deviation."""
+    the reference separates its two best classes by more than twice the measured deviation.
+    gate = (name, probabilities, bound): the gate is taken against THESE probabilities instead (quantised files: the oracle on the same
+    dequantised weights -- the reference's q8_0-activation semantics is reported, not gated: it differs from itself by more than the bound)."""
+    if gate is not None:
+        gname, gp, gbound = gate
+        dg = float(np.abs(got - gp).max())
+        srt = np.sort(gp, 1)
+        decided = (srt[:, -1] - srt[:, -2]) > 2 * dg
+        same = got.argmax(1) == gp.argmax(1)
+        par = {"rows": int(got.shape[0]), "max_dprob_vs_ref": float(np.abs(got - ref_p).max()), gname: dg, "gated_on": gname, "bound": gbound,
+               "top1_equal": bool(same.all()), "top1_equal_where_decided": bool(same[decided].all()), "rows_decided": int(decided.sum()),
+               "top1_prob_range": [round(float(gp.max(1).min()), 3), round(float(gp.max(1).max()), 3)]}
+        if extra:
+            par.update({k: v for k, v in extra.items() if k not in par})
+        par["passed"] = bool(dg <= gbound and par["top1_equal_where_decided"])
+        return par
     d = float(np.abs(got - ref_p).max())
     srt = np.sort(ref_p, 1)
     decided = (srt[:, -1] - srt[:, -2]) > 2 * d
@@ -192,6 +217,50 @@ def parity_of(np, got, ref_p, bound, extra=None):
         par.update(extra)
     par["passed"] = bool(d <= bound and par["top1_equal_where_decided"])
     return par
+
+
+def config1(np, torch, pkg, binding, O, device, st, stream, reps=25):
+    """BASELINE.json config 1: vit_tiny_patch16_224, batch 1, tests/golden/assets/tench.jpg (a copy of the reference's assets/tench.jpg).
+    CPU: the oracle (ggml-semantics restatement, NOT ggml) on the preprocessed image, median of `reps`; GPU: the same image, F16 parity mode,
+    host call -> synchronize, median of `reps`.  Random-init weights: the class is meaningless, the latency is not."""
+    path = pkg.synth.cached_synthetic("vit_tiny_patch16_224", head_scale=4.0)
+    jpg = os.path.join(ROOT, "tests", "golden", "assets", "tench.jpg")
+    u8 = binding.load_image(jpg)
+    t0 = time.perf_counter(); x = binding.preprocess(u8, 224)[None]; t_pre = time.perf_counter() - t0
+    res = {"workload": "vit_tiny_patch16_224, batch 1, tests/golden/assets/tench.jpg (%dx%d), bicubic preprocess, random-init weights" % (u8.shape[1], u8.shape[0]),
+           "reference_published": {"ms": 120, "what": "vit-tiny, ggml CPU path, /root/reference/README.md:190 (the author's laptop: another machine, real weights)"},
+           "host_preprocess_ms": round(t_pre * 1e3, 3)}
+    m = binding.Model(path)
+    c = binding.Context(m, device=device, max_batch=1, dtype=binding.F16)
+    d_in = torch.from_numpy(x).to("cuda"); d_out = torch.empty((1, m.num_classes), device="cuda")
+    for _ in range(5):
+        c.forward_device(d_in.data_ptr(), 1, d_out.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); c.forward_device(d_in.data_ptr(), 1, d_out.data_ptr(), 0, stream); torch.cuda.synchronize(); lat.append(time.perf_counter() - t0)
+    lat.sort()
+    res["gpu"] = {"latency_ms_median": round(lat[len(lat) // 2] * 1e3, 4), "latency_ms_min": round(lat[0] * 1e3, 4), "reps": reps, "dtype": "f16 (parity mode)",
+                  "what": "vitx_forward_device enqueue -> hipDeviceSynchronize on a device-resident preprocessed image"}
+    got = d_out.cpu().numpy()
+    if O is not None:
+        om = O.OracleModel(path)
+        res["cpu"] = {"kind": "port", "reps": reps, "what": "oracle/vit_oracle.c: restatement of the ggml CPU path with its rounding points, NOT ggml (the submodule is absent); "
+                                                              "4 threads = the reference's default (vit_params.n_threads, vit.h:95-103), then every host thread"}
+        all_threads = O.num_threads()
+        for nt in (4, all_threads):
+            O.set_num_threads(nt)
+            cl = []
+            for _ in range(reps):
+                t0 = time.perf_counter(); _, rp = om.forward(x, O.REF); cl.append(time.perf_counter() - t0)
+            cl.sort()
+            res["cpu"][f"threads_{nt}"] = {"latency_ms_median": round(cl[len(cl) // 2] * 1e3, 3), "latency_ms_min": round(cl[0] * 1e3, 3)}
+        O.set_num_threads(all_threads)
+        res["max_dprob_gpu_vs_oracle"] = float(np.abs(got - rp).max())
+        res["top1_equal"] = bool(got.argmax(1)[0] == rp.argmax(1)[0])
+        om.close()
+    c.close(); m.close()
+    return res
 
 
 def main():
@@ -370,6 +439,12 @@ def main():
         c.profile_enable(False)
         return pr
     prof = [] if (args.no_profile or stub) else profiled_step(ctx, B, imgs, torch.empty_like(probs))
+    def bracket_of(c):
+        try:
+            return c.profile_bracket_us()
+        except Exception:
+            return 0.0
+    bracket_us = bracket_of(ctx) if prof else 0.0
 
     def timed_rate(c, n_img, d_in, d_out, steps, warm):
         """images/s of `steps` forwards of context c, measured like the primary (warm-up, synchronize, K steps, synchronize)."""
@@ -436,7 +511,7 @@ def main():
             traffic, traffic_src = (None, "not measured (--no-pmc / --no-extras / N > 1)")
             if extras and not args.no_pmc:
                 traffic, traffic_src = measure_traffic(args.model, B, args.dtype)
-            roof, table = roofline_of(prof, 1, traffic, traffic_src)
+            roof, table = roofline_of(prof, 1, traffic, traffic_src, bracket_us)
             out["roofline"] = roof
             if traffic is None:
                 old, old_src = committed_traffic()
@@ -548,7 +623,7 @@ def main():
                         "gflop_per_image": round(gf, 4), "mfma_roofline_frac_whole_forward": round(rate * gf / 1e3 / PEAK_TFLOPS, 4), "weight_bytes_hbm": c_.weight_bytes()}
                 got_all = d_out.cpu().numpy()
                 pr = profiled_step(c_, batch, d_in, torch.empty_like(d_out))
-                roof, table = roofline_of(pr, 1, None, "not measured for this configuration")
+                roof, table = roofline_of(pr, 1, None, "not measured for this configuration", bracket_of(c_))
                 line["roofline"] = roof; line["kernel_breakdown"] = table
                 if sustain_s > 0:
                     n_s = max(30, int(sustain_s / (ms * 1e-3)))
@@ -567,18 +642,24 @@ def main():
                     ex = {"row_ids": rows_, "sub_batches": c_.split(batch)}
                     _, xp = om_.forward(ci, dataclasses.replace(O.REF, dot_exact=1))
                     ex["noise_floor"] = float(np.abs(xp - rp).max())
+                    gate = None
                     if dtype_name == "bf16":
                         _, sp = om_.forward(ci, O.GPU_BF16)           # (quant_act = 0: on a quantised file this is the dequantised-weights oracle in bf16)
                         ex["max_dprob_vs_bf16_oracle"] = float(np.abs(got_all[rows_] - sp).max())
                         bnd = max(BOUND_BF16, 10 * ex["noise_floor"])
+                        if ftype_name != "f16":       # what the parity tests assert for this mode (tests/test_gpu_parity_r03.py): the bf16-rounding oracle on the dequantised weights
+                            gate = ("max_dprob_vs_bf16_oracle", sp, BOUND_Q_BF16)
                     else:
                         bnd = max(BOUND_F16_FLOOR, 2 * ex["noise_floor"])
                         if ftype_name != "f16":
-                            _, dq = om_.forward(ci, dataclasses.replace(O.REF, quant_act=0))
-                            ex["max_dprob_vs_dequantised_oracle"] = float(np.abs(got_all[rows_] - dq).max())
+                            dq_mode = dataclasses.replace(O.REF, quant_act=0)
+                            _, dq = om_.forward(ci, dq_mode)
+                            _, dqx = om_.forward(ci, dataclasses.replace(dq_mode, dot_exact=1))
+                            ex["noise_floor_dequantised_oracle"] = float(np.abs(dqx - dq).max())
+                            gate = ("max_dprob_vs_dequantised_oracle", dq, max(BOUND_F16_FLOOR, 2 * ex["noise_floor_dequantised_oracle"]))
                     if ftype_name != "f16":
-                        ex["ref_is"] = "the reference's block semantics: q8_0-quantised activations x the file's blocks, integer inner sums (oracle REF, quant_act = 1)"
-                    line["parity"] = parity_of(np, got_all[rows_], rp, bnd, ex)
+                        ex["ref_is"] = "the reference's block semantics: q8_0-quantised activations x the file's blocks, integer inner sums (oracle REF, quant_act = 1); reported, not gated: it is not reproducible against itself below ~5e-3 (DESIGN 7)"
+                    line["parity"] = parity_of(np, got_all[rows_], rp, bnd, ex, gate)
                     om_.close()
                 c_.close(); m_.close()
                 return line
@@ -600,15 +681,22 @@ def main():
             # (3) BASELINE.json configs 5 and 3, measured like the primary (fewer steps), each with oracle rows of its own batch
             others = {}
             for key, a_ in ((f"{args.model} q4_0 file bs={B} {args.dtype}", dict(name=args.model, batch=B, ftype_name="q4_0", dtype_name=args.dtype, steps=10, warm=3, n_rows=6, d_in=imgs)),
+                            (f"{args.model} q4_0 file bs={B} f16", dict(name=args.model, batch=B, ftype_name="q4_0", dtype_name="f16", steps=10, warm=3, n_rows=6, d_in=imgs)),
                             (f"vit_large_patch16_384 bs=128 {args.dtype}", dict(name="vit_large_patch16_384", batch=128, ftype_name="f16", dtype_name=args.dtype, steps=8, warm=2, n_rows=4))):
                 try:
                     others[key] = secondary(**a_)
                     par = others[key].get("parity")
                     if par is not None and not par["passed"]:
-                        failed.append(f"{key} outside its parity bound: {par['max_dprob_vs_ref']:.3e} > {par['bound']:.3e} or a decided top-1 differs")
+                        failed.append(f"{key} outside its parity bound: {par[par.get('gated_on', 'max_dprob_vs_ref')]:.3e} > {par['bound']:.3e} or a decided top-1 differs")
                 except Exception as e:
                     others[key] = {"error": str(e)}
             out["other_configs"] = others
+            # (4) BASELINE.json config 1: ViT-tiny, ONE image (the reference's bundled assets/tench.jpg), batch 1 -- the one figure comparable
+            # with a number the reference publishes (README: 120 ms for vit-tiny on its author's laptop CPU)
+            try:
+                out["config1"] = config1(np, torch, pkg, binding, oracle_ctx[0] if oracle_ctx else None, local_rank, st, stream)
+            except Exception as e:
+                out["config1"] = {"error": str(e)}
             out["extras_wall_s"] = round(time.perf_counter() - extras_t0, 1)
         if failed:
             out["invalid"] = "parity gate failed: " + "; ".join(failed)

@@ -282,23 +282,27 @@ long long vitx_ctx_ln_fallbacks(vitx_ctx *c);
 int vitx_ctx_stream_retries(const vitx_ctx *c);
 /* 1 = norm2 / the next norm1 are computed in the proj / fc2 GEMMs' epilogues where the shape allows it (the default on an 8-XCD device); 0 = every
  * LayerNorm is its own launch (option no_ln_fusion, graph cache, a device that does not report 8 XCDs); -1 = the context switched the fusion off
- * itself because more than 8 tiles per forward (averaged over 16 forwards) had to fall back -- peers' CUs held by other work.  Same bits in all cases. */
+ * itself because more than 8 tiles per forward (averaged over 16 forwards) had to fall back -- peers' CUs held by other work; it tries the fused
+ * path again after a cool-down of 256 forwards (doubled on every further trip, at most 65536).  Same bits in all cases. */
 int vitx_ctx_ln_fusion_active(const vitx_ctx *c);
 /* out[n_img*N][D] (dtype) = softmax(q k^T / sqrt(64)) v per head from qkv[n_img*N][3D] (vit.cpp:826-866). */
 int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* kernel 0 = automatic, 1 = single-pass kernel (N <= 224, 257-288 or 577-608 tokens only),
  * 3 = pipelined two-pass kernel (any N; LDS-DMA double buffering, transposed LDS reads), 4 = persistent single-pass kernel (193..224
  * tokens: one workgroup per CU walks the (image, head) items, the next item's K/V land by LDS-DMA while the current one is computed).
- * Kernels 1 and 3 give bit-identical results; kernel 4 issues v_mfma_f32_16x16x32 instead of 32x32x16 (same products, another
- * accumulation grouping: equal within f32 summation noise).
+ * F16: kernels 1 and 3 give bit-identical results (both apply the fp16 exp table relative to the TRUE row maximum).  BF16: they do not --
+ * kernel 3 keeps a RUNNING maximum and rounds its numerators at another scale (equal within the numerators' bf16 rounding, 4e-3 relative in
+ * the tests), and the automatic choice switches from kernel 1 / 4 to kernel 3 above 288 tokens: a bf16 result depends on the kernel family
+ * the token count selects, not on the batch.  Kernel 4 issues v_mfma_f32_16x16x32 instead of 32x32x16 (same products, another accumulation
+ * grouping: equal within f32 summation noise).
  * kernel 5 = streaming two-pass kernel (attention_stream.hip; any N, head dim 64: v_mfma_f32_16x16x32, 64-key chunks through a 3-slot LDS-DMA ring). */
 int vitx_op_attention_ex(int dtype, int kernel, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* The F16 parity mode's attention on f32 q, k, v (the reference multiplies f32 operands, vit.cpp:848,858): d_qkv_f32 [n_img * N][3 D] f32 is
  * split into hi / lo fp16 planes (what the QKV GEMM's epi 5 emits) and every product is hi.hi + (hi.lo + lo.hi) / 2048.  d_out [n_img * N][D]
- * fp16.  Head dim 64.  Synchronous. */
+ * fp16.  Head dim 64.  TEST-ONLY entry point: it allocates and frees its own scratch and synchronises `stream` on every call. */
 int vitx_op_attention_f32(const float *d_qkv_f32, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* The same kernel on planes that are already split (the output of vitx_op_gemm_ex epi 5): d_hi [n_img * N][3 D] fp16, the lo plane lo_off
- * ELEMENTS behind it.  Only enqueues on `stream`. */
+ * ELEMENTS behind it (a multiple of 4, at least n_img * N * 3 D, both planes below 0xf0000000 bytes).  Only enqueues on `stream`. */
 int vitx_op_attention_planes(const void *d_hi, long lo_off, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* probs = softmax(logits) over num_classes with the reference's fp16 exp rounding (vit.cpp:931). */
 int vitx_op_softmax(const void *d_logits, void *d_probs, int rows, int cols, int ld, void *stream);

@@ -78,6 +78,7 @@ def lib():
         L.oracle_preprocess_vitstr.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, fp]
         L.oracle_model_in_chans.argtypes = [C.c_void_p]; L.oracle_model_out_rows.argtypes = [C.c_void_p]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_num_threads.restype = C.c_int; L.oracle_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -190,3 +191,8 @@ def preprocess_vitstr(img_u8: np.ndarray, S: int) -> np.ndarray:
 
 def num_threads() -> int:
     return lib().oracle_num_threads()
+
+
+def set_num_threads(n: int) -> int:
+    """Threads of the following oracle calls (the reference's vit_params.n_threads); returns the previous value."""
+    return lib().oracle_set_num_threads(int(n))

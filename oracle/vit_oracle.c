@@ -654,5 +654,16 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+/* Threads of the following calls (the reference's own knob: vit_params.n_threads, default 4 -- /root/reference/vit.h:95-103);
+ * returns the previous value. */
+int oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    const int prev = omp_get_max_threads();
+    if (n > 0) omp_set_num_threads(n);
+    return prev;
+#else
+    (void)n; return 1;
+#endif
+}
 /* quantize_row_q4_0_reference etc. are restated in vit.cpp_amd's own quantize tool
  * tests; the oracle only needs the decode side. */

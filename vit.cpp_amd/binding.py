@@ -103,7 +103,8 @@ def lib():
         L.vitx_topk.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.vitx_profile_enable.argtypes = [vp, ip]
         L.vitx_profile_read.argtypes = [vp, C.POINTER(ProfEntry), ip, C.POINTER(ip)]
-        L.vitx_profile_bracket_us.argtypes = [vp, C.POINTER(C.c_double)]
+        if hasattr(L, "vitx_profile_bracket_us"):      # (tools/ab_libs.py also loads builds that predate it)
+            L.vitx_profile_bracket_us.argtypes = [vp, C.POINTER(C.c_double)]
         L.vitx_op_layernorm.argtypes = [ip, vp, vp, vp, vp, ip, ip, C.c_float, vp]
         L.vitx_op_gemm.argtypes = [ip, ip, vp, vp, vp, vp, ip, ip, ip, vp]
         L.vitx_op_attention.argtypes = [ip, vp, vp, ip, ip, ip, ip, vp]

@@ -121,6 +121,9 @@ struct vitx_ctx {
     unsigned long long ln_fb_base = 0;   // counter total at the start of the current window
     int ln_fb_forwards = 0;
     bool ln_fuse_disabled = false;       // the budget tripped (vitx_ctx_ln_fusion_active)
+    // ... and is re-armed after a cool-down (r04 advisor: one burst of contention -- another context warming up -- must not cost the fused path
+    // for the rest of the context's life): the fusion is tried again after ln_cool_len forwards; every further trip doubles the cool-down (cap 2^16)
+    int ln_cool_left = 0, ln_cool_len = 256;
     // activations: the batch is cut into `nslices` contiguous sub-batches, each with its own scratch and HIP stream,
     // so that the tail round / launch gaps / epilogues of one sub-batch's kernels are filled by the other's
     // (measured +10 % images/s at batch 256, tools/two_stream_probe.py).  Sub-batches are independent images.
@@ -367,7 +370,8 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     if (opt.ln_test) {
         if ((opt.ln_test & (int32_t)0xffff0000) != (int32_t)VITX_LN_TEST_KEY) { set_error("vitx_ctx_create_ex: ln_test is a test-only switch (it needs its key: include/vitx.h)"); return VITX_ERR_ARG; }
         c->ln_test = opt.ln_test & 0xffff;
-        if (c->ln_test == 3) c->ln_timeout = 5000;       // real time-outs in the test: 50 us
+        if (c->ln_test & ~7) { set_error("vitx_ctx_create_ex: ln_test mode %d has bits outside 1 | 2 | 4", c->ln_test); return VITX_ERR_ARG; }
+        if ((c->ln_test & 3) == 3) c->ln_timeout = 5000;       // real time-outs in the test: 50 us (with or without bit 4; the kernel tests the bits one by one too)
     }
     c->ln_fuse = !opt.no_ln_fusion && !opt.graph;        // a captured launch would replay its epoch tag: no fusion under the graph cache
 #ifdef VITX_LAB
@@ -861,13 +865,24 @@ int vitx_forward_device(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, v
     return VITX_OK;
 }
 static int forward_pass(vitx_ctx *c, const void *d_imgs, int n, void *d_probs, void *d_logits, hipStream_t st) {
-    if (c->ln_fuse && c->ln_fb_host && (!c->ln_test || (c->ln_test & 4))) {       // fall-back budget of the fused LayerNorm (the counters are what the PREVIOUS forwards copied out; test mode: only with bit 4)
+    // Fall-back budget of the fused LayerNorm.  The counters are what the PREVIOUS forwards copied to pinned memory behind their last kernel
+    // (no event between that copy and this read: a value that is one forward stale, or mid-update, moves the decision by one window at most --
+    // the reads are volatile so that each is one 32-bit load).  Test mode: only with bit 4.
+    if (c->ln_fb_host && (!c->ln_test || (c->ln_test & 4))) {
         constexpr int kLnWindow = 16, kLnBudget = 8;
-        if (++c->ln_fb_forwards >= kLnWindow) {
-            unsigned long long total = 0;
-            for (int i = 0; i < c->nslices && i < 4; ++i) total += c->ln_fb_host[i];
-            if (total - c->ln_fb_base > (unsigned long long)kLnWindow * kLnBudget) { c->ln_fuse = false; c->ln_fuse_disabled = true; }
-            c->ln_fb_base = total; c->ln_fb_forwards = 0;
+        auto counters = [&]() { unsigned long long t = 0; for (int i = 0; i < c->nslices && i < 4; ++i) t += *(volatile unsigned *)(c->ln_fb_host + i); return t; };
+        if (c->ln_fuse) {
+            if (++c->ln_fb_forwards >= kLnWindow) {
+                const unsigned long long total = counters();
+                if (total - c->ln_fb_base > (unsigned long long)kLnWindow * kLnBudget) {
+                    c->ln_fuse = false; c->ln_fuse_disabled = true;
+                    c->ln_cool_left = c->ln_cool_len; c->ln_cool_len = std::min(c->ln_cool_len * 2, 1 << 16);
+                }
+                c->ln_fb_base = total; c->ln_fb_forwards = 0;
+            }
+        } else if (c->ln_fuse_disabled && --c->ln_cool_left <= 0) {       // cool-down over: try the fused path again (same bits either way)
+            c->ln_fuse = true; c->ln_fuse_disabled = false;
+            c->ln_fb_base = counters(); c->ln_fb_forwards = 0;
         }
     }
     // while per-kernel profiling is on, sub-batches run back to back on the caller's stream so that every
@@ -1130,7 +1145,12 @@ int vitx_op_attention(int dtype, const void *qkv, void *out, int n_img, int N, i
 // The precise kernel on planes that are already split (what the QKV GEMM's epilogue 5 emits): d_hi [n_img * N][3 D] fp16, the lo plane lo_off
 // ELEMENTS behind it.  Only enqueues on `stream`.
 int vitx_op_attention_planes(const void *d_hi, long lo_off, void *out, int n_img, int N, int D, int H, void *stream) {
-    if (!d_hi || !out || n_img <= 0 || N <= 0 || lo_off <= 0) return VITX_ERR_ARG;
+    if (!d_hi || !out || n_img <= 0 || N <= 0 || D <= 0 || H <= 0) { set_error("vitx_op_attention_planes: invalid argument"); return VITX_ERR_ARG; }
+    // the lo plane lies a whole number of 4-element groups behind the hi plane's rows and inside the 32-bit byte window the kernels address
+    if (lo_off < (long)n_img * N * 3 * D || lo_off % 4 != 0 || (size_t)lo_off * 2 + (size_t)n_img * N * 3 * D * 2 > 0xf0000000u) {
+        set_error("vitx_op_attention_planes: lo_off %ld must be a multiple of 4 elements, at least n_img * N * 3 * D = %ld, and keep both planes below 0xf0000000 bytes", lo_off, (long)n_img * N * 3 * D);
+        return VITX_ERR_ARG;
+    }
     if (!tuning_for_device(-1)) { set_error("vitx_op_attention_planes: kernel bring-up failed"); return VITX_ERR_HIP; }
     if (!attention_stream_supports(n_img, N, D, H)) { set_error("vitx_op_attention_planes: head_dim must be 64"); return VITX_ERR_UNSUPPORTED; }
     hipError_t e = launch_attention_stream(DT_F16, true, d_hi, out, n_img, N, D, H, lo_off, (hipStream_t)stream);
@@ -1140,7 +1160,7 @@ int vitx_op_attention_planes(const void *d_hi, long lo_off, void *out, int n_img
 // The parity mode's attention on f32 q, k, v (what the reference multiplies, vit.cpp:848,858): splits the rows into the two fp16 planes the
 // QKV GEMM's EPI_BIAS_HILO epilogue emits, then runs the precise streaming kernel.  Synchronous (allocates its own scratch).
 int vitx_op_attention_f32(const float *qkv_f32, void *out, int n_img, int N, int D, int H, void *stream) {
-    if (!qkv_f32 || !out || n_img <= 0 || N <= 0) return VITX_ERR_ARG;
+    if (!qkv_f32 || !out || n_img <= 0 || N <= 0 || D <= 0 || H <= 0) { set_error("vitx_op_attention_f32: invalid argument"); return VITX_ERR_ARG; }
     if (!tuning_for_device(-1)) { set_error("vitx_op_attention_f32: kernel bring-up failed"); return VITX_ERR_HIP; }
     if (!attention_stream_supports(n_img, N, D, H)) { set_error("vitx_op_attention_f32: head_dim must be 64"); return VITX_ERR_UNSUPPORTED; }
     const size_t n = (size_t)n_img * N * 3 * D;

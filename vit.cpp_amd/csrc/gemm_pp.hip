@@ -37,6 +37,25 @@
 #ifndef PP_MAX_VGPR
 #define PP_MAX_VGPR 128
 #endif
+// Cache-policy bits (buffer aux: 2 = nt) of the tensors one launch writes and ONE later launch reads once: QKV (qkv -> attention) and the MLP
+// hidden tensor H (fc1 -> fc2) are stored and fetched non-temporally, so that they stream through the L2s / the Infinity Cache instead of
+// evicting what is re-read: the residual stream X, the normalised rows and the weights -- also those of the OTHER sub-batch stream's kernel.
+// r05 A/B, six interleaved rounds on one box (profiles/r05/ab_cache_policy.txt): 9.705 ms default policy everywhere, H alone 9.63, QKV alone
+// 9.69, both 9.55 / 9.48 (+1.7 % images/s; every kernel is a little SLOWER alone -- 11.0 -> 11.7 ms of exclusive time -- the gain is what the
+// two streams stop taking from each other).  nt on the A streams of qkv / fc1 (the normalised rows, which nine / twelve column tiles
+// re-read from L2) costs 6 %: PP_AUX_A stays 0.
+#ifndef PP_AUX_QKV
+#define PP_AUX_QKV 2            // stores of the EPI_BIAS / EPI_BIAS_HILO epilogue (qkv -> attention)
+#endif
+#ifndef PP_AUX_H
+#define PP_AUX_H 2              // stores of the EPI_BIAS_GELU epilogue (fc1 -> fc2)
+#endif
+#ifndef PP_AUX_A_LNF
+#define PP_AUX_A_LNF 2          // A-operand LDS-DMA of the LayerNorm-fusing launches (proj: the attention output, fc2: H)
+#endif
+#ifndef PP_AUX_A
+#define PP_AUX_A 0              // A-operand LDS-DMA of every other launch (qkv, fc1: the normalised rows)
+#endif
 #ifndef PP_RESID_DEPTH
 #define PP_RESID_DEPTH 1        // passes the residual rows of the LayerNorm-fusing epilogue are requested ahead (r04 A/B: 1 = 3 = 5 = 7, profiles/r04/ab_resid_depth.txt)
 #endif
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         char *base = smem + lds_off + wave * 1024;
         const int so = (is_a + is_kt * BK + h * a_half) * 2;
 #pragma unroll
-        for (int i = 0; i < STAGE_OPS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, LPTR(base + i * 8192), 16, aoff[i] * 2, so, 0, 0);
+        for (int i = 0; i < STAGE_OPS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, LPTR(base + i * 8192), 16, aoff[i] * 2, so, 0, LNF ? PP_AUX_A_LNF : PP_AUX_A);
     };
     auto stage_w = [&](int h, int lds_off) {
         char *base = smem + lds_off + wave * 1024;
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
             // buffer op in a waterfall loop over the (uniform) SGPR offset
             if constexpr (LNF) relaxed = pp_epilogue_ln<T>(g, ln, acc16, rsrcO, smem, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, tid, m0, n0, ntn);
             else {
-                epilogue16_staged<T, EPI, 4>(acc16, bq, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane, (int)(g.hilo_off * esz));
+                epilogue16_staged<T, EPI, 4, (EPI == EPI_BIAS_GELU ? PP_AUX_H : ((EPI == EPI_BIAS || EPI == EPI_BIAS_HILO) ? PP_AUX_QKV : 0))>(acc16, bq, rsrcO, smem + LDS + wave * 4096, voff, __builtin_amdgcn_readfirstlane((m0 * g.ldo + n0) * esz), 8 * g.ldo * esz, lane, (int)(g.hilo_off * esz));
                 relaxed = true;
             }
         } else {

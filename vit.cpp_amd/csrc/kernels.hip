@@ -819,6 +819,9 @@ static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, i
 }
 
 // ------------------------------------------------------------------------------------------------
+#ifndef ATT_AUX
+#define ATT_AUX 2               // cache-policy bits of the persistent attention kernel's K / V LDS-DMA: nt -- QKV is read once (gemm_pp.hip "Cache-policy bits", profiles/r05/ab_cache_policy.txt)
+#endif
 #ifndef PERSIST_SUM_MFMA
 #define PERSIST_SUM_MFMA 1
 #endif
@@ -887,11 +890,11 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
     }
     auto stage = [&](int item, char *buf) {
         const int so = __builtin_amdgcn_readfirstlane((int)item_base(item));          // the buffer unit takes the SGPR offset as 32 unsigned bits
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + wave * 1024), 16, koff0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + wave * 1024), 16, voff0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + wave * 1024), 16, koff0, so, 0, ATT_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + wave * 1024), 16, voff0, so, 0, ATT_AUX);
         if (second) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + NTHR * 16 + wave * 1024), 16, koff0, so + (NTHR / 8) * row_bytes, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + NTHR * 16 + wave * 1024), 16, voff0, so + (NTHR / 8) * row_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + NTHR * 16 + wave * 1024), 16, koff0, so + (NTHR / 8) * row_bytes, 0, ATT_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(buf + KB + NTHR * 16 + wave * 1024), 16, voff0, so + (NTHR / 8) * row_bytes, 0, ATT_AUX);
         }
     };
     // Q fragments (B operand of S^T = K . Q^T): lane (l15 = query of the tile, g4) holds dims k2 * 32 + g4 * 8 .. + 7
