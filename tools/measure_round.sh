@@ -5,6 +5,7 @@
 tag=${1:-rXX}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag; mkdir -p $out
+python bench.py > $out/bench_default.json 2> $out/bench_default.err          # exactly what the driver runs
 python bench.py --steps 30 --warmup 10 > $out/bench_bf16.json 2> $out/bench_bf16.err
 python bench.py --steps 30 --warmup 10 --dtype f16 --no-cpu-baseline --no-extras > $out/bench_f16.json 2> $out/bench_f16.err
 python bench.py --steps 30 --warmup 10 --ftype q4_0 --no-extras > $out/bench_q4_0.json 2> $out/bench_q4_0.err
@@ -18,6 +19,9 @@ python tools/rocpd_summary.py $(find $out/prof $out/pmc1 $out/pmc2 -name "*.db" 
 python tools/hbm_traffic.py $(find $out/pmc1 -name "*.db" | head -1) $(find $out/pmc2 -name "*.db" | head -1) --commit "${COMMIT:-unknown}" --out $out/hbm_traffic.json > $out/hbm_traffic.log 2>&1
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/profL -o fwd -- python $R/tools/prof_forward.py vit_large_patch16_384 128 3 bf16 profile=1 > $R/$out/profL.log 2>&1 )
 python tools/rocpd_summary.py $(find $out/profL -name "*.db" | sort) > $out/rocprofv3_summary_large384.txt 2>&1
+# the bench line against a kernel trace of THE SAME COMMAND (does the calibrated event clock agree with the device's dispatch stamps?)
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $R/$out/bt -o b -- python $R/bench.py --no-extras --no-cpu-baseline > $R/$out/bench_same_run_as_rocprof.json 2> $R/$out/bt.log )
+python tools/bench_trace_agreement.py $(find $out/bt -name "*.db" | head -1) $out/bench_same_run_as_rocprof.json > $out/bench_under_rocprofv3.txt 2>&1
 # small-batch latency table: f16 file and q4_0 file (blocks in HBM), bf16 compute
 for ft in f16 q4_0; do for b in 1 8 32 64; do TF_FTYPE=$ft python tools/time_fwd.py $b vit_base_patch16_224 bf16 100 2>&1 | grep -v amdgpu; done; done > $out/small_batches.txt
 find $out -name "*.db" -size +20M -delete
@@ -26,4 +30,4 @@ import json
 for l in open("$out/bench.jsonl"):
     d = json.loads(l); print(d["config"]["workload"][:60], d["value"], d["ms_per_step"], d.get("roofline", {}).get("frac"))
 PY
-head -14 $out/rocprofv3_summary.txt; cat $out/hbm_traffic.json | head -14
+head -14 $out/rocprofv3_summary.txt; cat $out/hbm_traffic.json | head -14; cat $out/bench_under_rocprofv3.txt

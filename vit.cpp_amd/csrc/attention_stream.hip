@@ -55,7 +55,7 @@ constexpr int KB = CK * 128;         // bytes of one 64-row plane image (K or V 
 #define AS_CLAIM 1
 #endif
 #ifndef AP_AUX
-#define AP_AUX 0          // cache-policy bits of attention_precise_kernel's Q / K / V LDS-DMA (2 = nt)
+#define AP_AUX 2          // cache-policy bits of attention_precise_kernel's Q / K / V LDS-DMA: nt -- the two QKV planes are read once (F16 forward 11.20 -> 11.07 ms, profiles/r05/ab_cache_policy2.txt)
 #endif
 #ifndef AS_PARANOID
 #define AS_PARANOID 0

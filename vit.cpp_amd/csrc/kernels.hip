@@ -822,6 +822,9 @@ static hipError_t launch_attention_flow(const void *qkv, void *out, int n_img, i
 #ifndef ATT_AUX
 #define ATT_AUX 2               // cache-policy bits of the persistent attention kernel's K / V LDS-DMA: nt -- QKV is read once (gemm_pp.hip "Cache-policy bits", profiles/r05/ab_cache_policy.txt)
 #endif
+#ifndef ATT_OUT_AUX
+#define ATT_OUT_AUX 0           // cache-policy bits of the persistent attention kernel's output stores (read once, by proj)
+#endif
 #ifndef PERSIST_SUM_MFMA
 #define PERSIST_SUM_MFMA 1
 #endif
@@ -1093,7 +1096,7 @@ __device__ __forceinline__ void attention_persist_loop(const T *__restrict__ qkv
                 const auto lo = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, elo), __builtin_bit_cast(unsigned, olo), false, false);
                 const auto hi = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, ehi), __builtin_bit_cast(unsigned, ohi), false, false);
                 if (FLAGS & 4) { if (lo[0] == 0x12345678u && hi[1] == 0x9abcdef0u) out[off] = (T)1.0f; continue; }       // keeps the values alive, never true
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lo[0], hi[0], lo[1], hi[1]}, rsrc_o, (int)(off + pr * 64), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lo[0], hi[0], lo[1], hi[1]}, rsrc_o, (int)(off + pr * 64), 0, ATT_OUT_AUX);
             }
         }
         VITX_STAMP(4)
