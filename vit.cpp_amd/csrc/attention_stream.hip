@@ -54,6 +54,9 @@ constexpr int KB = CK * 128;         // bytes of one 64-row plane image (K or V 
 #ifndef AS_CLAIM
 #define AS_CLAIM 1
 #endif
+#ifndef AP_DROP
+#define AP_DROP 0         // numerics experiment (r04 verdict item 3; profiles/r05/precise_attention_dropped_terms.txt): 1 = no k_lo . q_hi products, 2 = no P . v_lo products
+#endif
 #ifndef AP_AUX
 #define AP_AUX 2          // cache-policy bits of attention_precise_kernel's Q / K / V LDS-DMA: nt -- the two QKV planes are read once (F16 forward 11.20 -> 11.07 ms, profiles/r05/ab_cache_policy2.txt)
 #endif
@@ -619,8 +622,10 @@ __global__ __launch_bounds__(1024, 4) void attention_precise_kernel(const _Float
         a = Elem<T>::mfma16(k1, qh[1], a);
         c = Elem<T>::mfma16(k0, ql[0], c);
         c = Elem<T>::mfma16(k1, ql[1], c);
-        c = Elem<T>::mfma16(l0, qh[0], c);
-        c = Elem<T>::mfma16(l1, qh[1], c);
+        if constexpr ((AP_DROP & 1) == 0) {
+            c = Elem<T>::mfma16(l0, qh[0], c);
+            c = Elem<T>::mfma16(l1, qh[1], c);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = __builtin_fmaf(c[r], kHiLoInv, a[r]);
         return a;
@@ -641,7 +646,7 @@ __global__ __launch_bounds__(1024, 4) void attention_precise_kernel(const _Float
             const s8 both = __builtin_shufflevector(vf[dt][0], vf[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
             o[dt] = Elem<T>::mfma16(__builtin_bit_cast(v8, both), p, o[dt]);
             const s8 bl = __builtin_shufflevector(vl[dt][0], vl[dt][1], 0, 1, 2, 3, 4, 5, 6, 7);
-            oc[dt] = Elem<T>::mfma16(__builtin_bit_cast(v8, bl), p, oc[dt]);
+            if constexpr ((AP_DROP & 2) == 0) oc[dt] = Elem<T>::mfma16(__builtin_bit_cast(v8, bl), p, oc[dt]);
         });
     };
     typedef std::integral_constant<int, 0> I0; typedef std::integral_constant<int, 2> I2;
