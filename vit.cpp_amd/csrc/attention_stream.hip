@@ -5,7 +5,7 @@
 //     v_mfma_f32_16x16x32 (the GEMMs' instruction), a wave owns TWO 16-query tiles so every K / V^T fragment read from LDS feeds two products
 //     (one fragment per product is exactly the LDS peak: 1 KiB per 16-cycle MFMA per SIMD = 256 B/clk/CU), a three-slot ring of 64-key chunks
 //     filled by LDS-DMA two chunks ahead with counted vmcnt and one raw barrier per chunk, every LDS read inline asm with counted lgkmcnt, row
-//     reductions by permlane swaps, 16-byte output stores; 16 waves x 128 VGPRs.  MEASURED SLOWER than attention_flow_kernel at 577 tokens
+//     reductions by permlane swaps, 16-byte output stores; 8 waves x 256 VGPRs (r04: 16 x 128, measured equal).  MEASURED SLOWER than attention_flow_kernel at 577 tokens
 //     (250 vs 212 us, profiles/r04/attention_577_ablation.txt): it is kernel id 5 (tests, lab) and NOT what the forward runs in bf16.
 //   * precise (QT = 1, PREC = true; f16 only): the F16 PARITY MODE at every token count.  The reference multiplies f32 q, k, v
 //     (ggml_mul_mat on f32 views, vit.cpp:848,858); r03 rounded them to fp16 for the MFMAs -- the one known semantic deviation of that
@@ -28,7 +28,7 @@ namespace vitx {
 
 namespace as {
 #ifndef AS_W
-#define AS_W 16         // waves per workgroup of the fast and the resident-score builds
+#define AS_W 8          // waves per workgroup of the fast build (r05: 8 x 256 registers -- at 16 x 128 it spilled 25 registers, and a spill is a vector-memory operation inside its counted vmcnt schedule)
 #endif
 #ifndef AS_OCC
 #define AS_OCC 4        // waves per SIMD the fast build is compiled for (the pipelined step, AS_PIPE, needs 194 VGPRs: AS_OCC 2)

@@ -22,7 +22,7 @@ namespace {
 struct DequantArgs { DequantJob job[4]; int first[5]; int njobs; };   // first[j] = global id of job j's first (padded) block
 
 template <int QT> struct QInfo;
-template <> struct QInfo<QT_Q4_0> { static constexpr int BB = 16; };   // nibble plane only: the scales are a separate plane
+template <> struct QInfo<QT_Q4_0> { [[maybe_unused]] static constexpr int BB = 16; };   // nibble plane only: the scales are a separate plane (dequant_q4_0_kernel expands this type)
 template <> struct QInfo<QT_Q4_1> { static constexpr int BB = 20; };
 template <> struct QInfo<QT_Q5_0> { static constexpr int BB = 22; };
 template <> struct QInfo<QT_Q5_1> { static constexpr int BB = 24; };
@@ -101,11 +101,46 @@ __global__ __launch_bounds__(256) void dequant_kernel(DequantArgs a) {
     }
 }
 
+// q4_0 (BASELINE config 5: one launch per layer and sub-batch stream in front of the qkv GEMM) with FOUR lanes per block: lane quarter q
+// expands elements 8 q .. 8 q + 7 -- bytes 8 (q & 1) .. + 7 of the nibble plane, low nibbles for q < 2, high nibbles above (ggml's
+// dequantize_row_q4_0 order) -- and writes ONE 16-byte piece, so a wave's store instruction covers 1 KiB of consecutive bytes instead of
+// 64 pieces at a 64-byte stride.  Same arithmetic per element, (float)(nibble - 8) * d rounded once: the same bits as dequant_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void dequant_q4_0_kernel(DequantArgs a) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int blk_id = gid >> 2, q = gid & 3;
+    if (blk_id >= a.first[a.njobs]) return;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (k < a.njobs && blk_id >= a.first[k]) j = k;
+    const DequantJob &job = a.job[j];
+    const int b = blk_id - a.first[j];
+    const int row = b / job.nbk, kb = b - row * job.nbk;
+    typename Elem<T>::v8 v;
+    if (row >= job.N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (T)0.0f;
+    } else {
+        const size_t blk = (size_t)row * job.nbk + kb;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 w = *(const u32x2 *)((const unsigned char *)job.src + blk * 16 + (q & 1) * 8);
+        const float d = h2f(((const uint16_t *)job.scales)[blk]);
+        const int sh = (q >> 1) * 4;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned byte = (w[e >> 2] >> ((e & 3) * 8)) & 0xffu;
+            v[e] = (T)((float)((int)((byte >> sh) & 15u) - 8) * d);
+        }
+    }
+    *(typename Elem<T>::v8 *)((T *)job.dst + ((size_t)row * job.nbk + kb) * 32 + q * 8) = v;
+}
+
 template <typename T, int QT>
 hipError_t launch_dequant_inst(const DequantArgs &a, hipStream_t stream) {
     const int total = a.first[a.njobs];
     if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL((dequant_kernel<T, QT>), dim3((total + 255) / 256), dim3(256), 0, stream, a);
+    if constexpr (QT == QT_Q4_0) hipLaunchKernelGGL((dequant_q4_0_kernel<T>), dim3((int)(((long)total * 4 + 255) / 256)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((dequant_kernel<T, QT>), dim3((total + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 template <typename T>
@@ -131,7 +166,7 @@ hipError_t launch_dequant(int dtype, int qtype, const DequantJob *jobs, int njob
         if (!jobs[j].src || !jobs[j].dst || jobs[j].nbk <= 0 || jobs[j].n_pad < jobs[j].N || (qtype == QT_Q4_0 && !jobs[j].scales)) return hipErrorInvalidValue;
         a.job[j] = jobs[j]; a.first[j] = (int)total;
         total += (long)jobs[j].n_pad * jobs[j].nbk;
-        if (total > 0x7fffffffL) return hipErrorInvalidValue;
+        if (total > 0x1fffffffL) return hipErrorInvalidValue;      // (x 4 lanes per block in the q4_0 kernel's thread index)
     }
     for (int j = njobs; j <= 4; ++j) a.first[j] = (int)total;
     return dtype == DT_F16 ? launch_dequant_t<_Float16>(qtype, a, stream) : launch_dequant_t<__bf16>(qtype, a, stream);
