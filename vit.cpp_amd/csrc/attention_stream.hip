@@ -57,6 +57,9 @@ constexpr int KB = CK * 128;         // bytes of one 64-row plane image (K or V 
 #ifndef AP_DROP
 #define AP_DROP 0         // numerics experiment (r04 verdict item 3; profiles/r05/precise_attention_dropped_terms.txt): 1 = no k_lo . q_hi products, 2 = no P . v_lo products
 #endif
+#ifndef AP_K2
+#define AP_K2 1           // K fragments of both 16-key tiles of a 32-key step in flight (16 more registers, still no spill): F16 forward 11.02 -> 10.94 ms, same bits (profiles/r05/ab_precise_k2.txt)
+#endif
 #ifndef AP_AUX
 #define AP_AUX 2          // cache-policy bits of attention_precise_kernel's Q / K / V LDS-DMA: nt -- the two QKV planes are read once (F16 forward 11.20 -> 11.07 ms, profiles/r05/ab_cache_policy2.txt)
 #endif
@@ -605,9 +608,12 @@ __global__ __launch_bounds__(1024, 4) void attention_precise_kernel(const _Float
     };
     const int q_chunk = (wave >> 2) * SLOT + ((wave & 3) >> 1) * 4096;      // this wave's 16 query rows inside the Q region: chunk wave >> 2, 16-row tile wave & 3 of it
 
-    // K fragments of ONE 16-key tile (both planes): the resident-score build of attention_stream_kernel read two tiles at a time; here the 16
-    // registers that saves are what keeps the item loop free of spills (a spill is a vector-memory operation inside a counted vmcnt schedule)
+    // K fragments of one 16-key tile (both planes); AP_K2: the step's second tile is requested into its own registers at the same time and
+    // copied over when its turn comes.  The item loop must stay free of spills: a spill is a vector-memory operation inside a counted vmcnt schedule
     i4 kf[2], kl[2];
+#if AP_K2
+    i4 kf2[2], kl2[2];      // the second 16-key tile of a 32-key step is requested together with the first
+#endif
     auto read_k = [&](unsigned sb, auto ks_, auto j_) {
         constexpr int ks = decltype(ks_)::value, j = decltype(j_)::value;
 #pragma unroll
@@ -706,8 +712,22 @@ __global__ __launch_bounds__(1024, 4) void attention_precise_kernel(const _Float
                             static_for<0, 2>([&](auto j_) {
                                 constexpr int j = decltype(j_)::value, t = 4 * c + 2 * ks + j;
                                 if constexpr (t < RES) {
+#if AP_K2
+                                    if constexpr (j == 0) {
+                                        read_k(sb, ks_, j_);
+                                        if constexpr (t + 1 < RES) {
+#pragma unroll
+                                            for (int k2 = 0; k2 < 2; ++k2) { ds_read_b128<ks * 4096>(kf2[k2], sb + krd[1][k2]); ds_read_b128<ks * 4096 + KB>(kl2[k2], sb + krd[1][k2]); }
+                                            wait_lgkm4<4>(kf[0], kf[1], kl[0], kl[1]);
+                                        } else wait_lgkm4<0>(kf[0], kf[1], kl[0], kl[1]);
+                                    } else {
+                                        wait_lgkm4<0>(kf2[0], kf2[1], kl2[0], kl2[1]);
+                                        kf[0] = kf2[0]; kf[1] = kf2[1]; kl[0] = kl2[0]; kl[1] = kl2[1];
+                                    }
+#else
                                     read_k(sb, ks_, j_);
                                     wait_lgkm4<0>(kf[0], kf[1], kl[0], kl[1]);
+#endif
                                     f32x4 sc = score();
                                     if constexpr (t >= 12) {            // only the tiles past key 191 can hold padded keys (N > 192)
                                         int l = lane; asm volatile("" : "+v"(l));
