@@ -100,3 +100,33 @@ def test_bench_refuses_development_overrides():
     env = dict(os.environ, VITX_SKIP="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "development overrides" in (r.stderr + r.stdout)
+
+
+def test_bench_gate_and_roofline_arithmetic():
+    """The pure-Python pieces of bench.py that decide a line's validity and its roofline object (r05): the parity gate taken against the
+    same-semantics oracle for a quantised file (the reference's q8_0-activation figure is reported, not gated), and the per-kernel clock
+    with the measured bracket cost subtracted from every launch."""
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    rng = np.random.default_rng(0)
+    ref = rng.dirichlet(np.ones(10) * 0.3, size=6).astype(np.float32)
+    same = ref + 1e-4                      # what the engine's own semantics gives
+    got = same + 3e-4
+    far = np.roll(ref, 1, axis=1)          # "the reference's block semantics": far away
+    par = bench.parity_of(np, got, far, 2e-2, {"row_ids": [0]}, gate=("max_dprob_vs_dequantised_oracle", same, 1e-3))
+    assert par["passed"] and par["gated_on"] == "max_dprob_vs_dequantised_oracle" and par["bound"] == 1e-3
+    assert abs(par["max_dprob_vs_dequantised_oracle"] - 3e-4) < 1e-6 and par["max_dprob_vs_ref"] > 0.05 and par["row_ids"] == [0]
+    par = bench.parity_of(np, got, far, 2e-2, None, gate=("max_dprob_vs_dequantised_oracle", same, 1e-4))
+    assert not par["passed"]
+    par = bench.parity_of(np, got, same, 1e-3)
+    assert par["passed"] and "gated_on" not in par
+    prof = [dict(name="gemm_fc2_resid", launches=24, total_ms=3.30, busy_ms=3.30, flops=2.856e12, bytes=8.4e9),
+            dict(name="gemm_qkv_bias", launches=24, total_ms=2.2, busy_ms=2.2, flops=2.14e12, bytes=3.7e9),
+            dict(name="attention", launches=24, total_ms=1.0, busy_ms=1.0, flops=3.7e11, bytes=3.7e9)]
+    roof, table = bench.roofline_of(prof, 1, {"gemm_fc2_resid": 0.417}, "pmc", bracket_us=5.0)
+    assert roof["kernel"] == "gemm_fc2_resid" and roof["bracket_us"] == 5.0
+    assert abs(roof["avg_launch_ms"] - (3.30 - 24 * 0.005) / 24) < 1e-4 and abs(roof["avg_launch_ms_raw_event_interval"] - 3.30 / 24) < 1e-4
+    assert abs(roof["achieved"] - 2.856e12 / ((3.30 - 0.12) * 1e-3) / 1e12) < 0.1 and roof["achieved"] > roof["achieved_raw_event_interval"]
+    assert abs(table["attention"]["us_per_launch"] - (1.0 - 0.12) / 24 * 1e3) < 0.01 and "HIP events" in roof["clock"]
