@@ -41,6 +41,11 @@ FTYPES = {"f16": 1, "q4_0": 2, "q4_1": 3, "q5_0": 6, "q5_1": 7, "q8_0": 8}
 BOUND_BF16 = 2e-2
 BOUND_F16_FLOOR = 1e-3
 BOUND_Q_BF16 = 6e-3        # bf16 forward of a quantised file vs the bf16-rounding oracle on the same dequantised weights
+# Every number of this script except `class_rows_last_layer` is measured on the reference's WHOLE graph: every token row of every layer
+# (vit.cpp:805-900 for all L layers).  The engine's default skips the rows of the LAST layer that cannot reach the output (only the class token's row
+# is read, vit.cpp:910-911; vitx_ctx_options::last_layer_all_rows) -- an algorithmic saving, not kernel throughput, so it is reported beside the
+# metric and never as `value`.
+ALL_ROWS = {"last_layer_all_rows": 1}
 
 
 def committed_traffic():
@@ -74,7 +79,7 @@ def measure_traffic(model, batch, dtype, timeout=150):
     dbs = []
     for tag, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", os.path.join(tmp, tag), "-o", "t", "--",
-               sys.executable, os.path.join(ROOT, "tools", "prof_forward.py"), model, str(batch), "2", dtype, "profile=1"]
+               sys.executable, os.path.join(ROOT, "tools", "prof_forward.py"), model, str(batch), "2", dtype, "profile=1,last_layer_all_rows=1"]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
         except Exception as e:
@@ -231,7 +236,7 @@ def config1(np, torch, pkg, binding, O, device, st, stream, reps=25):
            "reference_published": {"ms": 120, "what": "vit-tiny, ggml CPU path, /root/reference/README.md:190 (the author's laptop: another machine, real weights)"},
            "host_preprocess_ms": round(t_pre * 1e3, 3)}
     m = binding.Model(path)
-    c = binding.Context(m, device=device, max_batch=1, dtype=binding.F16)
+    c = binding.Context(m, device=device, max_batch=1, dtype=binding.F16, **ALL_ROWS)
     d_in = torch.from_numpy(x).to("cuda"); d_out = torch.empty((1, m.num_classes), device="cuda")
     for _ in range(5):
         c.forward_device(d_in.data_ptr(), 1, d_out.data_ptr(), 0, stream)
@@ -344,7 +349,7 @@ def main():
         model, ctx = None, StubContext()
     else:
         model = binding.Model(path)
-        ctx = binding.Context(model, device=local_rank, max_batch=B, dtype=dt)
+        ctx = binding.Context(model, device=local_rank, max_batch=B, dtype=dt, **ALL_ROWS)
 
     # synthetic batch resident in HBM: u8 noise -> (v-mean)/std f32 HWC, what vit_image_preprocess emits
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
@@ -492,6 +497,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} {args.dtype} ({args.ftype} weight file), batch={B} per GPU, {S}x{S}x3 f32 HWC inputs in HBM, random-init weights in the reference's file format",
+                       "graph": "every token row of every layer, as the reference builds it (vit.cpp:805-900); the engine's default leaves out the last layer's rows that cannot reach the output: class_rows_last_layer",
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, replicated weights, 1 all-gather of probs/step)" if world > 1 else "single GPU"},
             "gflop_per_image": round(gflop, 4), "weights": args.ftype,
             "weight_bytes_hbm": ctx.weight_bytes(),
@@ -585,7 +591,7 @@ def main():
             # (1b) serving throughput with TWO forwards in flight: two contexts without the internal sub-batch split, whole batches from two
             # caller streams (tools/two_in_flight.py; the same kernels at twice the rows per launch, results bit-identical) -- NOT `value`
             try:
-                pair = [binding.Context(model, device=local_rank, max_batch=B, dtype=dt, streams=1) for _ in range(2)]
+                pair = [binding.Context(model, device=local_rank, max_batch=B, dtype=dt, streams=1, **ALL_ROWS) for _ in range(2)]
                 ref_probs_timed = probs.clone()       # what the timed context (two sub-batches) wrote for the same images
                 pp_ = [torch.empty_like(probs), torch.empty_like(probs)]
                 sts = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -611,7 +617,7 @@ def main():
                 h_ = pkg.synth.hparams_for(name)
                 m_ = binding.Model(p_)
                 dd = binding.BF16 if dtype_name == "bf16" else binding.F16
-                c_ = binding.Context(m_, device=local_rank, max_batch=batch, dtype=dd, **(ctx_opts or {}))
+                c_ = binding.Context(m_, device=local_rank, max_batch=batch, dtype=dd, **{**ALL_ROWS, **(ctx_opts or {})})
                 if d_in is None:
                     gg = torch.Generator(device="cpu").manual_seed(99)
                     uu = torch.randint(0, 256, (batch, h_.img_size, h_.img_size, 3), generator=gg, dtype=torch.uint8)
@@ -622,6 +628,7 @@ def main():
                 line = {"value": round(rate, 1), "unit": "images/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warm, "dtype": dtype_name, "weights": ftype_name,
                         "gflop_per_image": round(gf, 4), "mfma_roofline_frac_whole_forward": round(rate * gf / 1e3 / PEAK_TFLOPS, 4), "weight_bytes_hbm": c_.weight_bytes()}
                 got_all = d_out.cpu().numpy()
+                line["_probs"] = got_all
                 pr = profiled_step(c_, batch, d_in, torch.empty_like(d_out))
                 roof, table = roofline_of(pr, 1, None, "not measured for this configuration", bracket_of(c_))
                 line["roofline"] = roof; line["kernel_breakdown"] = table
@@ -665,6 +672,7 @@ def main():
                 return line
 
             # (2) the parity mode (fp16 operands: the reference's rounding points) measured exactly like the primary, on the same batch
+            pm_probs = None
             if args.dtype == "bf16":
                 try:
                     # the SAME rows, reference probabilities and noise floor as the primary's parity object
@@ -672,11 +680,32 @@ def main():
                                    reuse=(oracle_ctx[1], oracle_ctx[3], oracle_ctx[4]) if oracle_ctx is not None else None, sustain_s=min(args.sustain_s, 4.0))
                     if "parity" in pm and not pm["parity"]["passed"]:
                         failed.append(f"F16 parity mode outside its bound: {pm['parity']['max_dprob_vs_ref']:.3e} > max(1e-3, 2 x noise floor {oracle_ctx[4]:.3e}) or a decided top-1 differs")
+                    pm_probs = pm.pop("_probs", None)
                     pm["what"] = "VITX_F16: fp16 MFMA operands, f32-grade attention products, the reference's fp16 exp / GELU rounding points; timed like `value`, profiled like `roofline`"
                     out["parity_mode"] = pm
                 except Exception as e:
                     out["parity_mode"] = {"error": str(e)}
                     failed.append(f"parity mode did not run: {e}")
+            # (2b) the engine's DEFAULT: past the last qkv projection only the class-token row of each image is carried on (vit.cpp:910-911 reads no other
+            # row, and no other row can reach it).  Same images, same rows against the same reference probabilities.  Not `value`: the gain is work
+            # not done (0.84 of one layer), not kernel throughput.
+            try:
+                crl = {}
+                for dn in ((args.dtype, "f16") if args.dtype == "bf16" else (args.dtype,)):
+                    ln_ = secondary(args.model, B, "f16", dn, args.steps, args.warmup, 0, d_in=imgs, ctx_opts={"last_layer_all_rows": 0},
+                                    reuse=(oracle_ctx[1], oracle_ctx[3], oracle_ctx[4]) if oracle_ctx is not None else None)
+                    if "parity" in ln_ and not ln_["parity"]["passed"]:
+                        failed.append(f"class-rows-only last layer ({dn}) outside its parity bound: {ln_['parity']['max_dprob_vs_ref']:.3e}")
+                    got_, full_p = ln_.pop("_probs"), (timed_probs if dn == args.dtype else pm_probs)
+                    if full_p is not None:      # all B images against the every-row forward of the same operand type
+                        ln_["max_dprob_vs_every_row_forward"] = float(np.abs(got_ - full_p).max())
+                        ln_["top1_equal_to_every_row_forward"] = bool((got_.argmax(1) == full_p.argmax(1)).all())
+                    crl[dn] = ln_
+                crl["what"] = ("vitx_ctx_options::last_layer_all_rows = 0 (the library's default): attention, output projection, norm2 and MLP of the LAST layer on one row per image; "
+                               "gflop_per_image and the roofline fractions of these lines still count the whole graph's flops -- executed work is 6.9 % less")
+                out["class_rows_last_layer"] = crl
+            except Exception as e:
+                out["class_rows_last_layer"] = {"error": str(e)}
             ctx.close()
             # (3) BASELINE.json configs 5 and 3, measured like the primary (fewer steps), each with oracle rows of its own batch
             others = {}
@@ -685,6 +714,7 @@ def main():
                             (f"vit_large_patch16_384 bs=128 {args.dtype}", dict(name="vit_large_patch16_384", batch=128, ftype_name="f16", dtype_name=args.dtype, steps=8, warm=2, n_rows=4))):
                 try:
                     others[key] = secondary(**a_)
+                    others[key].pop("_probs", None)
                     par = others[key].get("parity")
                     if par is not None and not par["passed"]:
                         failed.append(f"{key} outside its parity bound: {par[par.get('gated_on', 'max_dprob_vs_ref')]:.3e} > {par['bound']:.3e} or a decided top-1 differs")

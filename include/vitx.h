@@ -142,6 +142,11 @@ typedef struct vitx_ctx_options {
                                  fall-back budget (without it a test context keeps fusing whatever the count) */
     int32_t f16_fast_attention; /* VITX_F16 contexts: 1 = q, k, v rounded to fp16 for the attention products (the r03 behaviour: one QKV plane, the fast
                                  attention kernels) instead of the parity mode's f32-grade products (two fp16 planes, three MFMAs per product) */
+    int32_t last_layer_all_rows; /* 1 = the last encoder layer computes every token row, as the reference graph does (vit.cpp:805-900 for il = L - 1).
+                                 Default 0: past its qkv projection the last layer of a classifier carries only the class-token row of each image -- the only
+                                 row vit.cpp:910-911 reads, and no other row can reach it (rows meet only through k and v inside the attention).  Same
+                                 probabilities; 0.84 of one layer's work is not done (ViT-B: 6.9 % of the forward).  ViTSTR contexts and contexts with a
+                                 residual-stream trace always compute every row. */
 } vitx_ctx_options;
 #define VITX_LN_TEST_KEY 0x7e570000
 int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype, const vitx_ctx_options *options, vitx_ctx **out);
@@ -297,6 +302,10 @@ int vitx_op_attention(int dtype, const void *d_qkv, void *d_out, int n_img, int 
  * grouping: equal within f32 summation noise).
  * kernel 5 = streaming two-pass kernel (attention_stream.hip; any N, head dim 64: v_mfma_f32_16x16x32, 64-key chunks through a 3-slot LDS-DMA ring). */
 int vitx_op_attention_ex(int dtype, int kernel, const void *d_qkv, void *d_out, int n_img, int N, int D, int H, void *stream);
+/* Token 0 of every image only -- the one attention row the last layer of a classifier needs (vit.cpp:910-911): d_out [n_img][D] (dtype),
+ * softmax(q_0 k^T / sqrt(head_dim)) v per head with f32 products and the same numerator rounding as the kernels above.  lo_off != 0: d_qkv is
+ * the hi plane of the F16 parity mode and the lo plane lies lo_off elements behind it (multiple of 8; VITX_F16 only).  head_dim 8, 16, 32, 64, 128. */
+int vitx_op_attention_cls(int dtype, const void *d_qkv, long lo_off, void *d_out, int n_img, int N, int D, int H, void *stream);
 /* The F16 parity mode's attention on f32 q, k, v (the reference multiplies f32 operands, vit.cpp:848,858): d_qkv_f32 [n_img * N][3 D] f32 is
  * split into hi / lo fp16 planes (what the QKV GEMM's epi 5 emits) and every product is hi.hi + (hi.lo + lo.hi) / 2048.  d_out [n_img * N][D]
  * fp16.  Head dim 64.  TEST-ONLY entry point: it allocates and frees its own scratch and synchronises `stream` on every call. */

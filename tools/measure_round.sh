@@ -12,12 +12,12 @@ python bench.py --steps 30 --warmup 10 --ftype q4_0 --no-extras > $out/bench_q4_
 python bench.py --steps 20 --warmup 5 --model vit_large_patch16_384 --batch 128 --no-cpu-baseline --no-extras > $out/bench_large384.json 2> $out/bench_large384.err
 cat $out/bench_bf16.json $out/bench_f16.json $out/bench_q4_0.json $out/bench_large384.json > $out/bench.jsonl
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 5 bf16 profile=1 > $R/$out/prof.log 2>&1 )
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $R/$out/pmc1 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 profile=1 > $R/$out/pmc1.log 2>&1 )
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $R/$out/pmc2 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 profile=1 > $R/$out/pmc2.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 5 bf16 profile=1,last_layer_all_rows=1 > $R/$out/prof.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $R/$out/pmc1 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 profile=1,last_layer_all_rows=1 > $R/$out/pmc1.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $R/$out/pmc2 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 profile=1,last_layer_all_rows=1 > $R/$out/pmc2.log 2>&1 )
 python tools/rocpd_summary.py $(find $out/prof $out/pmc1 $out/pmc2 -name "*.db" | sort) > $out/rocprofv3_summary.txt 2>&1
 python tools/hbm_traffic.py $(find $out/pmc1 -name "*.db" | head -1) $(find $out/pmc2 -name "*.db" | head -1) --commit "${COMMIT:-unknown}" --out $out/hbm_traffic.json > $out/hbm_traffic.log 2>&1
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/profL -o fwd -- python $R/tools/prof_forward.py vit_large_patch16_384 128 3 bf16 profile=1 > $R/$out/profL.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/profL -o fwd -- python $R/tools/prof_forward.py vit_large_patch16_384 128 3 bf16 profile=1,last_layer_all_rows=1 > $R/$out/profL.log 2>&1 )
 python tools/rocpd_summary.py $(find $out/profL -name "*.db" | sort) > $out/rocprofv3_summary_large384.txt 2>&1
 # the bench line against a kernel trace of THE SAME COMMAND (does the calibrated event clock agree with the device's dispatch stamps?)
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $R/$out/bt -o b -- python $R/bench.py --no-extras --no-cpu-baseline > $R/$out/bench_same_run_as_rocprof.json 2> $R/$out/bt.log )

@@ -30,7 +30,7 @@ EXPORTS = [
     "vitx_ctx_create", "vitx_ctx_create_ex", "vitx_ctx_free", "vitx_ctx_max_batch", "vitx_forward", "vitx_forward_device", "vitx_ctx_synchronize",
     "vitx_topk", "vitx_group_create", "vitx_group_free", "vitx_group_num_devices", "vitx_group_forward", "vitx_group_out_floats", "vitx_group_forward_device", "vitx_group_result", "vitx_group_result_rows", "vitx_profile_enable", "vitx_profile_read", "vitx_profile_bracket_us", "vitx_op_layernorm", "vitx_op_gemm", "vitx_op_gemm_ex", "vitx_op_attention", "vitx_op_attention_ex", "vitx_op_softmax", "vitx_op_softmax_dt", "vitx_trace_enable", "vitx_trace_read",
     "vitx_op_dequant", "vitx_op_gemm_q4", "vitx_ctx_weight_bytes", "vitx_ctx_shares_weights", "vitx_probe_mfma", "vitx_op_gemm_ln", "vitx_ctx_ln_fallbacks", "vitx_ctx_stream_retries",
-    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_ctx_ln_fusion_active", "vitx_op_attention_f32", "vitx_op_attention_planes", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
+    "vitx_model_in_channels", "vitx_model_seq_len", "vitx_ctx_out_rows", "vitx_ctx_split", "vitx_ctx_ln_fusion_active", "vitx_op_attention_f32", "vitx_op_attention_planes", "vitx_op_attention_cls", "vitx_preprocess_vitstr_u8", "vitx_vitstr_decode",
 ]
 
 
@@ -41,7 +41,7 @@ class HParams(C.Structure):
 
 class CtxOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("streams", C.c_int32), ("graph", C.c_int32), ("quant_on_host", C.c_int32), ("q4_fused_rows", C.c_int32),
-                ("split_first", C.c_int32), ("no_ln_fusion", C.c_int32), ("ln_test", C.c_int32), ("f16_fast_attention", C.c_int32)]
+                ("split_first", C.c_int32), ("no_ln_fusion", C.c_int32), ("ln_test", C.c_int32), ("f16_fast_attention", C.c_int32), ("last_layer_all_rows", C.c_int32)]
 
 
 class ProfEntry(C.Structure):
@@ -127,6 +127,8 @@ def lib():
         L.vitx_ctx_ln_fusion_active.argtypes = [vp]
         L.vitx_op_attention_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp]
         L.vitx_op_attention_planes.argtypes = [vp, C.c_long, vp, ip, ip, ip, ip, vp]
+        if hasattr(L, "vitx_op_attention_cls"):
+            L.vitx_op_attention_cls.argtypes = [ip, vp, C.c_long, vp, ip, ip, ip, ip, vp]
         L.vitx_preprocess_vitstr_u8.argtypes = [C.POINTER(C.c_uint8), ip, ip, ip, C.POINTER(C.c_float)]
         L.vitx_vitstr_decode.argtypes = [C.POINTER(C.c_float), ip, ip, C.POINTER(C.c_int32), C.POINTER(ip), C.POINTER(C.c_double)]
         _lib = L

@@ -35,10 +35,10 @@ namespace {
 
 enum ProfClass {
     PC_GEMM_PATCH = 0, PC_LAYERNORM, PC_GEMM_QKV, PC_ATTENTION, PC_GEMM_PROJ, PC_GEMM_FC1, PC_GEMM_FC2,
-    PC_GEMM_HEAD, PC_SOFTMAX, PC_DEQUANT, PC_COUNT
+    PC_GEMM_HEAD, PC_SOFTMAX, PC_DEQUANT, PC_ATTENTION_CLS, PC_GEMM_TAIL, PC_COUNT
 };
 const char *kProfNames[PC_COUNT] = {"patch_embed", "layernorm", "gemm_qkv_bias", "attention", "gemm_proj_resid",
-                                    "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_head", "softmax", "dequant_weights"};
+                                    "gemm_fc1_gelu", "gemm_fc2_resid", "gemm_head", "softmax", "dequant_weights", "attention_cls", "gemm_cls_tail"};
 
 // A weight matrix kept in the file's block form on the device (quant.hip): `blocks` = N rows of K/32 blocks in the file's byte
 // layout -- except q4_0, which is split into a nibble plane (`blocks`, 16 B per block, rows padded to n_pad) and an f16 scale
@@ -108,6 +108,12 @@ struct vitx_ctx {
     // emits two fp16 planes (EPI_BIAS_HILO) and the precise streaming kernel multiplies hi.hi + (hi.lo + lo.hi) / 2048 (attention_stream.hip).
     // Head dim 64 only (the generic head-dim kernel keeps fp16 q, k, v).
     bool prec_attn = false;
+    // Last layer of a classifier: vit.cpp:910-911 reads row 0 of its output and nothing else, and rows meet each other only inside the attention
+    // (through k and v).  So after the last qkv projection only the class token's row is carried on: its attention (attention_cls_kernel), then the
+    // output projection, norm2 and the MLP on ONE row per image (Slice::Xc).  Same results; 0.84 of one layer's work is never asked for
+    // (ViT-B: 6.9 % of the forward).  vitx_ctx_options::last_layer_all_rows computes every row as the reference graph does (bench.py's headline does).
+    // Not taken by ViTSTR contexts (25 rows per image feed the head) or while a residual-stream trace is on (the trace shows every row).
+    bool cls_tail = true;
     bool ln_fuse = true;
     unsigned ln_epoch = 0;               // tag of the next fused launch (unique per launch; 0 is never used)
     unsigned ln_timeout = 20000;         // 200 us of the 100 MHz wall clock before a workgroup leaves its tile to the fix-up
@@ -138,6 +144,7 @@ struct vitx_ctx {
         void *QKV = nullptr;         // [Mpad][3D]; the parity mode's lo plane follows at qkv_lo_off elements
         long qkv_lo_off = 0;
         void *Hbuf = nullptr;        // [Mpad][4D]  (also the im2col rows of the patch-embed GEMM)
+        float *Xc = nullptr;         // [Bpad][D] f32 class-token rows of the residual stream through the last layer's tail (cls_tail)
         void *Z = nullptr;           // [Bpad][D] final-LN output of the cls rows
         void *Wq[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};   // just-in-time expansion of the current layer's quantised matrices
         void *Wq_head = nullptr;
@@ -335,7 +342,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     if (opt_in) {
         if (opt_in->struct_size < 8 || opt_in->struct_size > (int)sizeof(vitx_ctx_options)) { set_error("vitx_ctx_create_ex: options.struct_size %d is not a size this library knows", opt_in->struct_size); return VITX_ERR_ARG; }
         memcpy(&opt, opt_in, (size_t)opt_in->struct_size);
-        if (opt.streams < 0 || opt.streams > 4 || opt.q4_fused_rows < 0 || opt.split_first < 0) { set_error("vitx_ctx_create_ex: option out of range"); return VITX_ERR_ARG; }
+        if (opt.streams < 0 || opt.streams > 4 || opt.q4_fused_rows < 0 || opt.split_first < 0 || (opt.last_layer_all_rows & ~1)) { set_error("vitx_ctx_create_ex: option out of range"); return VITX_ERR_ARG; }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("vitx_ctx_create: no HIP device available (this engine has no CPU fallback)"); return VITX_ERR_HIP; }
@@ -364,6 +371,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
     c->split_first = opt.split_first;
     c->prec_attn = dtype == VITX_F16 && c->D == c->H * 64 && !opt.f16_fast_attention;
     c->quant_on_device = !opt.quant_on_host;
+    c->cls_tail = !opt.last_layer_all_rows && c->R == 1 && attention_cls_supports(c->N, c->D, c->H);
     c->q4_fused_rows = opt.q4_fused_rows;
     c->graphs_on = opt.graph != 0;
     // fault injection for the parity tests: honoured only with the key in the upper half (VITX_LN_TEST_KEY | mode), so that no caller sets it by accident
@@ -467,6 +475,7 @@ int vitx_ctx_create_ex(const vitx_model *m, int device, int max_batch, int dtype
         sl.qkv_lo_off = c->prec_attn ? (long)(Mpad * 3 * D) : 0;       // capacity; a forward places the lo plane right behind ITS rows (forward_slice)
         if ((rc = c->dmalloc(&sl.Hbuf, Mpad * hcols * 2, true))) return rc;
         if ((rc = c->dmalloc(&sl.Z, Bpad * D * 2, true))) return rc;
+        if (c->cls_tail && (rc = c->dmalloc((void **)&sl.Xc, Bpad * D * 4, true))) return rc;
         if ((rc = c->dmalloc((void **)&sl.logits, Bpad * c->C_pad * 4, true))) return rc;
         // expansion scratch for quantised matrices: one buffer per matrix kind, shared by all layers (the largest layer decides)
         for (int k = 0; k < W_PER_LAYER; ++k) {
@@ -602,8 +611,11 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
         return VITX_OK;
     };
     GemmLn fix_u{}, fix_u2{};          // fused LayerNorm launches whose output (U / U2) has not been consumed yet
+    const bool tail = c->cls_tail && c->trace_ids.empty();      // the last layer carries only the class-token rows past its qkv projection (vitx_ctx::cls_tail)
+    const int Mc = round_up(n, tm);                             // rows of the tail GEMMs (n real ones)
     for (int il = 0; il < c->L; ++il) {
         const LayerW &w = c->layers[il];
+        const bool tail_now = tail && il + 1 == c->L;
         const void *Wl[W_PER_LAYER] = {w.qkv_w, w.proj_w, w.fc1_w, w.fc2_w};
         const QuantW *Fl[W_PER_LAYER] = {nullptr, nullptr, nullptr, nullptr};      // matrices the fused kernel takes
         {
@@ -611,7 +623,7 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
             bool any = false;
             for (int k = 0; k < W_PER_LAYER; ++k) {
                 if (!w.q[k].blocks) continue;
-                if (fused_ok(w.q[k], M)) Fl[k] = &w.q[k];
+                if (fused_ok(w.q[k], (tail_now && k != W_QKV) ? Mc : M)) Fl[k] = &w.q[k];
                 else { todo[k] = &w.q[k]; Wl[k] = sl.Wq[k]; any = true; }
             }
             if (any && (rc = expand(todo, sl.Wq, W_PER_LAYER))) return rc;
@@ -642,6 +654,21 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
 #endif
         if ((rc = gemm(c, tn_, st, PC_GEMM_QKV, (c->prec_attn && prec_dbg != 2) ? EPI_BIAS_HILO : EPI_BIAS, sl.U, Wl[W_QKV], w.qkv_b, sl.QKV, nullptr, M, M_real, 3 * D, round_up(3 * D, tn), D, D, D, 3 * D, 0, 2, Fl[W_QKV], nullptr,
                        fix_u.todo ? &fix_u : nullptr, lo_off))) return rc;
+        if (tail_now) {
+            {   // attention of token 0 (vit.cpp:848-858 for the one row vit.cpp:910-911 keeps) -> compact rows U[b]; class rows of X -> Xc[b]
+                ProfScope ps(c, st, PC_ATTENTION_CLS, 4.0 * n * c->H * (double)N * (D / c->H), (double)M_real * 2 * D * eb * (c->prec_attn ? 2 : 1) + (double)n * D * (eb + 8));
+                HIP_TRY(launch_attention_cls(dt, sl.QKV, lo_off, sl.U, sl.X, sl.Xc, n, N, D, c->H, st));
+            }
+            // output projection + residual, norm2, MLP (vit.cpp:868-900) on the n class rows
+            if ((rc = gemm(c, tn_, st, PC_GEMM_TAIL, EPI_BIAS_RESID, sl.U, Wl[W_PROJ], w.proj_b, sl.Xc, nullptr, Mc, n, D, round_up(D, tn), D, D, D, D, 0, 4, Fl[W_PROJ]))) return rc;
+            {
+                ProfScope ps(c, st, PC_LAYERNORM, 0, (double)n * D * (4 + eb));
+                HIP_TRY(launch_layernorm(dt, sl.Xc, D, w.ln2_w, w.ln2_b, sl.U2, D, n, D, c->hp.eps, st));
+            }
+            if ((rc = gemm(c, tn_, st, PC_GEMM_TAIL, EPI_BIAS_GELU, sl.U2, Wl[W_FC1], w.fc1_b, sl.Hbuf, nullptr, Mc, n, 4 * D, round_up(4 * D, tn), D, D, D, 4 * D, 0, 2, Fl[W_FC1]))) return rc;
+            if ((rc = gemm(c, tn_, st, PC_GEMM_TAIL, EPI_BIAS_RESID, sl.Hbuf, Wl[W_FC2], w.fc2_b, sl.Xc, nullptr, Mc, n, D, round_up(D, tn), 4 * D, 4 * D, 4 * D, D, 0, 4, Fl[W_FC2]))) return rc;
+            break;
+        }
         {   // attention (vit.cpp:826-866)
             ProfScope ps(c, st, PC_ATTENTION, 4.0 * n * c->H * (double)N * N * (D / c->H), (double)M_real * (c->prec_attn ? 7 : 4) * D * eb);
             if (!(skip & 1)) {
@@ -683,7 +710,8 @@ static int forward_slice(vitx_ctx *c, vitx_ctx::Slice &sl, hipStream_t st, const
     {
         ProfScope ps(c, st, PC_LAYERNORM, 0, (double)nR * D * (4 + eb));
         // classifier: one row per image, row stride N*D; ViTSTR: groups of R consecutive token rows (stride D), group stride N*D
-        HIP_TRY(launch_layernorm(dt, sl.X, c->R == 1 ? (long)N * D : (long)D, c->norm_w, c->norm_b, sl.Z, D, nR, D, c->hp.eps, st, c->R, (long)N * D));
+        if (tail) HIP_TRY(launch_layernorm(dt, sl.Xc, D, c->norm_w, c->norm_b, sl.Z, D, n, D, c->hp.eps, st));
+        else HIP_TRY(launch_layernorm(dt, sl.X, c->R == 1 ? (long)N * D : (long)D, c->norm_w, c->norm_b, sl.Z, D, nR, D, c->hp.eps, st, c->R, (long)N * D));
     }
     // classifier (vit.cpp:927-928) and class softmax (vit.cpp:931-933)
     float *lg = d_logits ? (float *)d_logits : sl.logits;
@@ -1155,6 +1183,19 @@ int vitx_op_attention_planes(const void *d_hi, long lo_off, void *out, int n_img
     if (!attention_stream_supports(n_img, N, D, H)) { set_error("vitx_op_attention_planes: head_dim must be 64"); return VITX_ERR_UNSUPPORTED; }
     hipError_t e = launch_attention_stream(DT_F16, true, d_hi, out, n_img, N, D, H, lo_off, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_attention_planes: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
+    return VITX_OK;
+}
+// Attention of token 0 of every image (the row the last layer of a classifier keeps, vit.cpp:910-911): out[n_img][D] (dtype).  lo_off != 0: the two
+// fp16 planes of the F16 parity mode (VITX_F16 only), as vitx_op_attention_planes takes them.  Only enqueues on `stream`.
+int vitx_op_attention_cls(int dtype, const void *d_qkv, long lo_off, void *out, int n_img, int N, int D, int H, void *stream) {
+    if (!d_qkv || !out || n_img <= 0 || N <= 0 || D <= 0 || H <= 0 || (dtype != VITX_F16 && dtype != VITX_BF16)) { set_error("vitx_op_attention_cls: invalid argument"); return VITX_ERR_ARG; }
+    if (lo_off && (dtype != VITX_F16 || lo_off < (long)n_img * N * 3 * D || lo_off % 8 != 0)) {
+        set_error("vitx_op_attention_cls: a lo plane needs VITX_F16 and lo_off %ld a multiple of 8 elements, at least n_img * N * 3 * D = %ld", lo_off, (long)n_img * N * 3 * D);
+        return VITX_ERR_ARG;
+    }
+    if (!attention_cls_supports(N, D, H)) { set_error("vitx_op_attention_cls: head_dim must be 8, 16, 32, 64 or 128 and N at most 16384 (head_dim %d, N %d)", D / H, N); return VITX_ERR_UNSUPPORTED; }
+    hipError_t e = launch_attention_cls(dtype == VITX_F16 ? DT_F16 : DT_BF16, d_qkv, lo_off, out, nullptr, nullptr, n_img, N, D, H, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("vitx_op_attention_cls: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
     return VITX_OK;
 }
 // The parity mode's attention on f32 q, k, v (what the reference multiplies, vit.cpp:848,858): splits the rows into the two fp16 planes the

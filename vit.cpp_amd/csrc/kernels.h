@@ -134,6 +134,10 @@ hipError_t launch_attention_stream(int dtype, bool precise, const void *qkv, voi
 bool attention_stream_supports(int n_img, int N, int D, int H);
 // x[n] f32 -> hi[n] = round(x), lo[n] = round((x - hi) * 2048) in the operand type (what EPI_BIAS_HILO emits; parity-test entry point)
 hipError_t launch_split_hilo(int dtype, const float *x, void *hi, void *lo, size_t n, hipStream_t stream);
+// Attention of token 0 only (the last layer of a classifier needs nothing else, vit.cpp:910-911): out[b][D] (dtype) from qkv[n_img * N][3 D]
+// (lo_off != 0: the parity mode's lo plane, F16 only); xc != nullptr: also xc[b][D] = x[b * N][D] (the class rows of the f32 residual stream)
+hipError_t launch_attention_cls(int dtype, const void *qkv, long lo_off, void *out, const float *x, float *xc, int n_img, int N, int D, int H, hipStream_t stream);
+bool attention_cls_supports(int N, int D, int H);  // head_dim 8, 16, 32, 64 or 128
 bool attention_supports(int N, int D, int H);     // any token count; head_dim 64 (tuned kernels) or any other multiple of 8 up to 128 (generic kernel)
 bool attention_single_pass_supports(int N);       // instantiation table of the register-resident kernel
 bool layernorm_supports(int D);

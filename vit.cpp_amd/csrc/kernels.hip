@@ -1283,6 +1283,132 @@ static hipError_t launch_attention_generic(const void *qkv, void *out, int n_img
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention of the class token alone (last encoder layer of a classifier).  vit.cpp:910-911 keeps row 0 of the last layer's output and
+// nothing else; inside a layer a token's row depends on the other tokens only through their k and v (vit.cpp:848-858).  So in the last layer
+// only q of token 0 meets K and V of all tokens, and the output projection and the MLP after it run on ONE row per image (engine.cpp).
+// One workgroup of four waves per (image, head).  A row of the head's K (or V) slice is NP 16-byte pieces; lane = (row group g, piece p): 64 / NP rows
+// per wave and step, the waves interleaved.
+//   pass 1: s_j = q . k_j in f32 (shuffle sum over the NP lanes of a row) -> LDS, and the row maximum;
+//   pass 2: e_j = the kernels' numerator rule (AttnExpRt: fp16 table semantics for F16, rounded bf16 otherwise), o += e_j v_j in f32, sum of e_j;
+//           the row groups are combined by shuffles, the four waves through LDS in index order; o / sum is rounded once to the operand type.
+// PLANES: the F16 parity mode's two-plane q, k, v (value = hi + lo / 2048, EPI_BIAS_HILO) -- here the products are plain f32 FMAs.
+// The workgroup of head h also copies the residual-stream slice X[b * N][h * DH ..] into the compact rows xc[b][..] the tail GEMMs work on.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NP, bool PLANES>
+__global__ __launch_bounds__(256) void attention_cls_kernel(const T *__restrict__ qkv, long lo_off, T *__restrict__ out, const float *__restrict__ x, float *__restrict__ xc,
+                                                            int N, int D, int H, float scale) {
+    extern __shared__ float cls_sc[];                  // [N] raw scores, then [4] wave maxima, [4] wave sums, [4][DH] wave partial outputs
+    typedef typename Elem<T>::v8 v8;
+    constexpr int DH = NP * 8, G = 64 / NP;            // G rows per wave and step; the four waves take rows 4 G apart
+    const int tid = threadIdx.x, lane = tid & 63, p = lane % NP, g = lane / NP;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x, b = item / H, h = item - b * H;
+    const size_t row_el = (size_t)3 * D;
+    const T *base = qkv + (size_t)b * N * row_el + (size_t)h * DH + p * 8;         // this lane's piece of q of token 0; k at + D, v at + 2 D
+    float *wmax = cls_sc + N, *wsum = wmax + 4, *wacc = wsum + 4;
+    auto load8 = [&](const T *ptr, float (&f)[8]) {
+        const v8 a = *(const v8 *)ptr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)a[e];
+        if (PLANES) {
+            const v8 l = *(const v8 *)(ptr + lo_off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = __builtin_fmaf((float)l[e], 1.0f / 2048.0f, f[e]);
+        }
+    };
+    if (xc && tid < DH / 4) *(f32x4 *)(xc + (size_t)b * D + h * DH + tid * 4) = *(const f32x4 *)(x + (size_t)b * N * D + h * DH + tid * 4);
+    float q[8];
+    load8(base, q);
+    float mx = -INFINITY;
+    const int steps2 = (N + 8 * G - 1) / (8 * G);      // two steps per trip: both rows' loads are in flight together
+    for (int it = 0; it < steps2; ++it) {
+        const int ra = (it * 8 + wave) * G + g, rb = ra + 4 * G;
+        float ka[8], kb[8];
+        load8(base + D + (size_t)min(ra, N - 1) * row_el, ka);
+        load8(base + D + (size_t)min(rb, N - 1) * row_el, kb);
+        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sa = __builtin_fmaf(q[e], ka[e], sa); sb = __builtin_fmaf(q[e], kb[e], sb); }
+#pragma unroll
+        for (int o = 1; o < NP; o <<= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+        if (ra < N) { mx = fmaxf(mx, sa); if (p == 0) cls_sc[ra] = sa; }
+        if (rb < N) { mx = fmaxf(mx, sb); if (p == 0) cls_sc[rb] = sb; }
+    }
+#pragma unroll
+    for (int o = NP; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) wmax[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float kk = AttnExpRt<T>::k(scale), nmx = -kk * mx;
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, sum = 0.0f;
+    for (int it = 0; it < steps2; ++it) {
+        const int ra = (it * 8 + wave) * G + g, rb = ra + 4 * G, rac = min(ra, N - 1), rbc = min(rb, N - 1);
+        float va[8], vb[8];
+        load8(base + 2 * D + (size_t)rac * row_el, va);
+        load8(base + 2 * D + (size_t)rbc * row_el, vb);
+        const typename Pair<T>::v2 e2 = AttnExpRt<T>::pair(cls_sc[rac], cls_sc[rbc], nmx, kk);
+        const float ea = ra < N ? (float)e2[0] : 0.0f, eb = rb < N ? (float)e2[1] : 0.0f;
+        sum += ea; sum += eb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i] = __builtin_fmaf(ea, va[i], acc[i]); acc[i] = __builtin_fmaf(eb, vb[i], acc[i]); }
+    }
+#pragma unroll
+    for (int o = NP; o < 64; o <<= 1) {
+        sum += __shfl_xor(sum, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], o);
+    }
+    if (g == 0) {
+        if (p == 0) wsum[wave] = sum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wacc[wave * DH + p * 8 + i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < NP) {                                    // lane = piece: waves combined in index order
+        const float inv = 1.0f / (((wsum[0] + wsum[1]) + wsum[2]) + wsum[3]);
+        v8 o8;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const int c = tid * 8 + i;
+            const float a0 = ((wacc[c] + wacc[DH + c]) + wacc[2 * DH + c]) + wacc[3 * DH + c];
+            const float a1 = ((wacc[c + 1] + wacc[DH + c + 1]) + wacc[2 * DH + c + 1]) + wacc[3 * DH + c + 1];
+            const typename Pair<T>::v2 pr = round_pair<T>(a0 * inv, a1 * inv);
+            o8[i] = pr[0]; o8[i + 1] = pr[1];
+        }
+        *(v8 *)(out + (size_t)b * D + h * DH + tid * 8) = o8;
+    }
+}
+bool attention_cls_supports(int N, int D, int H) {
+    if (H <= 0 || D % H || N <= 0 || N > 16384) return false;
+    const int dh = D / H;
+    return dh == 8 || dh == 16 || dh == 32 || dh == 64 || dh == 128;
+}
+template <typename T, bool PLANES>
+static hipError_t launch_attention_cls_t(const void *qkv, long lo_off, void *out, const float *x, float *xc, int n_img, int N, int D, int H, hipStream_t stream) {
+    const int np = D / H / 8;
+    const float scale = 1.0f / sqrtf((float)(D / H));
+    const dim3 grid((unsigned)((size_t)n_img * H)), blk(256);
+    const size_t lds = ((size_t)N + 8 + 4 * (D / H)) * sizeof(float);
+#define VITX_CLS(NP) hipLaunchKernelGGL((attention_cls_kernel<T, NP, PLANES>), grid, blk, lds, stream, (const T *)qkv, lo_off, (T *)out, x, xc, N, D, H, scale)
+    switch (np) {
+    case 1: VITX_CLS(1); break;
+    case 2: VITX_CLS(2); break;
+    case 4: VITX_CLS(4); break;
+    case 8: VITX_CLS(8); break;
+    case 16: VITX_CLS(16); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef VITX_CLS
+    return hipGetLastError();
+}
+hipError_t launch_attention_cls(int dtype, const void *qkv, long lo_off, void *out, const float *x, float *xc, int n_img, int N, int D, int H, hipStream_t stream) {
+    if (!attention_cls_supports(N, D, H) || n_img <= 0) return hipErrorInvalidValue;
+    if (lo_off && dtype != DT_F16) return hipErrorInvalidValue;
+    if (dtype == DT_F16) return lo_off ? launch_attention_cls_t<_Float16, true>(qkv, lo_off, out, x, xc, n_img, N, D, H, stream) : launch_attention_cls_t<_Float16, false>(qkv, 0, out, x, xc, n_img, N, D, H, stream);
+    return launch_attention_cls_t<__bf16, false>(qkv, 0, out, x, xc, n_img, N, D, H, stream);
+}
+
 bool attention_persist_supports(int n_img, int N, int D) { return N > 192 && N <= 224 && (size_t)n_img * N * 3 * D * 2 < 0xf0000000u; }
 
 static const int kAttnNkt[] = {1, 2, 3, 4, 5, 6, 7, 9, 19};      // instantiated key-tile counts (tokens = 32 * nkt, rounded up)
