@@ -1193,7 +1193,7 @@ int vitx_op_attention_cls(int dtype, const void *d_qkv, long lo_off, void *out, 
         set_error("vitx_op_attention_cls: a lo plane needs VITX_F16 and lo_off %ld a multiple of 8 elements, at least n_img * N * 3 * D = %ld", lo_off, (long)n_img * N * 3 * D);
         return VITX_ERR_ARG;
     }
-    if (!attention_cls_supports(N, D, H)) { set_error("vitx_op_attention_cls: head_dim must be 8, 16, 32, 64 or 128 and N at most 16384 (head_dim %d, N %d)", D / H, N); return VITX_ERR_UNSUPPORTED; }
+    if (!attention_cls_supports(N, D, H)) { set_error("vitx_op_attention_cls: head_dim must be 8, 16, 32, 64 or 128 and N at most 15360 (head_dim %d, N %d)", D / H, N); return VITX_ERR_UNSUPPORTED; }
     hipError_t e = launch_attention_cls(dtype == VITX_F16 ? DT_F16 : DT_BF16, d_qkv, lo_off, out, nullptr, nullptr, n_img, N, D, H, (hipStream_t)stream);
     if (e != hipSuccess) { set_error("vitx_op_attention_cls: %s", hipGetErrorString(e)); return VITX_ERR_HIP; }
     return VITX_OK;

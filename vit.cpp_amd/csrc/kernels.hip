@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(256) void attention_cls_kernel(const T *__restrict_
     }
 }
 bool attention_cls_supports(int N, int D, int H) {
-    if (H <= 0 || D % H || N <= 0 || N > 16384) return false;
+    if (H <= 0 || D % H || N <= 0 || N > 15360) return false;      // scores + the waves' partial sums stay inside 64 KiB of LDS
     const int dh = D / H;
     return dh == 8 || dh == 16 || dh == 32 || dh == 64 || dh == 128;
 }
