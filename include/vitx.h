@@ -128,7 +128,8 @@ int vitx_vitstr_decode(const float *probs, int seq_len, int num_classes, int32_t
  * The library reads NO environment variable: everything tunable is in vitx_ctx_options. */
 int vitx_ctx_create(const vitx_model *m, int device, int max_batch, int dtype, vitx_ctx **out);
 /* Options of a context; every field 0 = the default.  Set struct_size = sizeof(vitx_ctx_options) (lets the struct grow).
- * All of them change HOW the forward is scheduled or where weights live, never what it computes. */
+ * They change HOW the forward is scheduled or where weights live, not what it computes -- except f16_fast_attention and last_layer_all_rows, which
+ * select between two evaluations of the same graph that differ within the operand type's rounding (see the fields). */
 typedef struct vitx_ctx_options {
     int32_t struct_size;
     int32_t streams;          /* sub-batch streams, 1..4 (default 2; contexts for fewer than 8 images per stream use 1) */
