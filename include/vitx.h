@@ -146,7 +146,7 @@ typedef struct vitx_ctx_options {
     int32_t last_layer_all_rows; /* 1 = the last encoder layer computes every token row, as the reference graph does (vit.cpp:805-900 for il = L - 1).
                                  Default 0: past its qkv projection the last layer of a classifier carries only the class-token row of each image -- the only
                                  row vit.cpp:910-911 reads, and no other row can reach it (rows meet only through k and v inside the attention).  Same
-                                 probabilities; 0.84 of one layer's work is not done (ViT-B: 6.9 % of the forward).  ViTSTR contexts and contexts with a
+                                 probabilities; 0.76 of one layer's work is not done (ViT-B: 6.3 % of the forward's flops).  ViTSTR contexts and contexts with a
                                  residual-stream trace always compute every row. */
 } vitx_ctx_options;
 #define VITX_LN_TEST_KEY 0x7e570000

@@ -110,8 +110,8 @@ struct vitx_ctx {
     bool prec_attn = false;
     // Last layer of a classifier: vit.cpp:910-911 reads row 0 of its output and nothing else, and rows meet each other only inside the attention
     // (through k and v).  So after the last qkv projection only the class token's row is carried on: its attention (attention_cls_kernel), then the
-    // output projection, norm2 and the MLP on ONE row per image (Slice::Xc).  Same results; 0.84 of one layer's work is never asked for
-    // (ViT-B: 6.9 % of the forward).  vitx_ctx_options::last_layer_all_rows computes every row as the reference graph does (bench.py's headline does).
+    // output projection, norm2 and the MLP on ONE row per image (Slice::Xc).  Same results; 0.76 of one layer's work is never asked for
+    // (ViT-B: 6.3 % of the forward's flops).  vitx_ctx_options::last_layer_all_rows computes every row as the reference graph does (bench.py's headline does).
     // Not taken by ViTSTR contexts (25 rows per image feed the head) or while a residual-stream trace is on (the trace shows every row).
     bool cls_tail = true;
     bool ln_fuse = true;
