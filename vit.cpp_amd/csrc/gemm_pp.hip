@@ -71,7 +71,7 @@ constexpr int LDS = 8 * HALF;           // 128 KiB operand ring: [A0 A1 of buffe
 __host__ __device__ constexpr int off_a(int buf, int h) { return (buf * 2 + h) * HALF; }
 __host__ __device__ constexpr int off_b(int buf, int h) { return (4 + buf * 2 + h) * HALF; }
 constexpr int LDS_ALL = LDS + 8 * 4096; // + one 4 KiB epilogue patch per wave = all 160 KiB
-constexpr int GROUP_M = 8;
+constexpr int GROUP_M = 8;              // raster group height (row blocks) when the launcher does not choose one (GemmArgs::group_m)
 constexpr int STAGE_OPS = 2;            // LDS-DMA instructions per thread per half-tile
 constexpr int LEAD = 4;                 // stages allowed in flight past a phase's wait
 }  // namespace pp

@@ -209,6 +209,11 @@ bool gemm_fix_capable(const Tuning &t, const GemmArgs &a) {
 }
 static hipError_t launch_wide(const Tuning &t, int dtype, int epi, const GemmArgs &a0, hipStream_t stream) {
     GemmArgs a = a0; a.group_m = t.group_m;
+    // Raster of the qkv / fc1 launches (r05, profiles/r05/raster_sweep.txt): an XCD walks groups of group_m row blocks x all column tiles.  While the
+    // whole weight matrix fits beside the A panels in the XCD's 4 MiB L2 (+ a little: ViT-B qkv 3.4 MiB, fc1 4.5 MiB), group_m = 1 -- every CU of the
+    // XCD on the same few row blocks, W resident, A streamed once -- is 0.4-0.7 % of the ViT-B forward faster than 8 (two independent A/Bs, same
+    // bits); with ViT-L's matrices (6 / 8 MiB) it is 0.6 % slower, so they keep the A-resident groups of 8.
+    if (!a.group_m && !a.ln && (epi == EPI_BIAS || epi == EPI_BIAS_HILO || epi == EPI_BIAS_GELU)) a.group_m = ((size_t)a.N_pad * a.K * 2 <= ((size_t)5 << 20)) ? 1 : 8;
     if (a.ln) return (epi == EPI_BIAS_RESID && gemm_ln_fusable(t, a)) ? launch_gemm_pp(dtype, epi, a, t.n_cu, stream, 0) : hipErrorInvalidValue;
     if (gemm_pp_supports(a)) return launch_gemm_pp(dtype, epi, a, pp_grid(t, a), stream, t.pp_flags);
     return launch_gemm_ring(t, dtype, epi, a, wide_ring_cfg(a), stream);
