@@ -46,6 +46,121 @@ BOUND_Q_BF16 = 6e-3        # bf16 forward of a quantised file vs the bf16-roundi
 # is read, vit.cpp:910-911; vitx_ctx_options::last_layer_all_rows) -- an algorithmic saving, not kernel throughput, so it is reported beside the
 # metric and never as `value`.
 ALL_ROWS = {"last_layer_all_rows": 1}
+# class-token tail vs the every-row forward of the same operand type on all images of the batch: operand rounding only (recorded 1.1e-3 / 3.0e-4)
+CLS_TAIL_BOUND = {"bf16": 5e-3, "f16": 1e-3}
+
+
+EXTRAS_FILE = os.path.join(ROOT, "bench_extras.json")
+COMPACT_LIMIT = 6144      # bytes: the driver reads the LAST stdout line; r05's 28 KB line was not parsed
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short_parity(par):
+    """The gate of one configuration in five numbers: what was measured, against what, the bound, the verdict."""
+    if not isinstance(par, dict):
+        return None
+    s = _pick(par, ("max_dprob_vs_ref", "bound", "passed", "noise_floor", "rows", "rows_decided", "top1_equal_where_decided", "gated_on", "unverified"))
+    if "gated_on" in par:
+        s[par["gated_on"]] = par.get(par["gated_on"])
+    for k, v in list(s.items()):
+        if isinstance(v, float):
+            s[k] = float(f"{v:.3e}")
+    return s
+
+
+def _short_config(line):
+    """One secondary configuration: rate, step time, whole-forward fraction of the nominal MFMA peak, its dominant kernel's fraction, its gate."""
+    if not isinstance(line, dict) or "error" in line:
+        return line
+    s = _pick(line, ("value", "ms_per_step", "steps", "dtype", "weights"))
+    s["frac"] = line.get("mfma_roofline_frac_whole_forward")
+    if isinstance(line.get("roofline"), dict):
+        s["kernel"] = {"name": line["roofline"].get("kernel"), "frac": line["roofline"].get("frac"), "avg_launch_ms": line["roofline"].get("avg_launch_ms")}
+    if "parity" in line:
+        s["parity"] = _short_parity(line["parity"])
+    if "vs_reference_semantics" in line:
+        s["vs_reference_semantics"] = line["vs_reference_semantics"]
+    return s
+
+
+def compact_line(out):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, the gates, and one short summary per other
+    configuration.  Everything else of `out` (per-kernel tables, power series, row ids, prose) goes to bench_extras.json."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = out.get("config", {})
+    c["config"] = {"workload": cfg.get("workload_short", cfg.get("workload")), "graph": "whole reference graph (every token row of every layer)",
+                   "global_batch": cfg.get("global_batch"), "parallelism": cfg.get("parallelism")}
+    if "ranks" in cfg:
+        c["config"]["ranks"] = cfg["ranks"]
+    if "invalid" in out:
+        c["invalid"] = out["invalid"][:400]
+    c["frac_whole_forward"] = out.get("mfma_roofline_frac_whole_forward")
+    r = out.get("roofline")
+    if isinstance(r, dict):
+        c["roofline"] = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit", "avg_launch_ms", "flops_per_launch", "launches_per_step", "bracket_us"))
+        c["roofline"]["clock"] = "HIP events on the launch stream around every launch of one extra step, bracket cost subtracted"
+        probe = r.get("mfma_sustained_random_operands", {})
+        if "TFLOPs" in probe:
+            c["probe_tflops"] = probe["TFLOPs"]; c["probe_MHz"] = probe.get("shader_clock_MHz")
+    if "cpu_baseline" in out:
+        c["cpu_baseline"] = out["cpu_baseline"]
+    if "parity" in out:
+        c["parity"] = _short_parity(out["parity"])
+    kb = out.get("kernel_breakdown")
+    if isinstance(kb, dict):       # five largest classes: us per launch and share of the step's kernel time
+        top = sorted(kb.items(), key=lambda kv: -kv[1].get("share", 0))[:6]
+        c["kernels"] = {k: [v.get("us_per_launch"), v.get("share"), v.get("TFLOPs")] for k, v in top}
+        c["kernels_fields"] = "us_per_launch, share, TFLOP/s"
+    if "parity_mode" in out:
+        c["parity_mode"] = _short_config(out["parity_mode"])
+    if isinstance(out.get("other_configs"), dict):
+        c["other_configs"] = {k: _short_config(v) for k, v in out["other_configs"].items()}
+    crl = out.get("class_rows_last_layer")
+    if isinstance(crl, dict):
+        c["class_rows_last_layer"] = {k: ({"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "passed": (v.get("parity") or {}).get("passed"),
+                                            "max_dprob_vs_every_row_forward": v.get("max_dprob_vs_every_row_forward")} if isinstance(v, dict) else v)
+                                      for k, v in crl.items() if k != "what"}
+        c["class_rows_last_layer"]["note"] = "library default (dead rows of the last layer skipped): work not done, never `value`"
+    c1 = out.get("config1")
+    if isinstance(c1, dict):
+        c["config1"] = {"workload": "vit_tiny bs 1 tench.jpg", "gpu_ms": (c1.get("gpu") or {}).get("latency_ms_median"),
+                        "cpu_port_ms": {k: v.get("latency_ms_median") for k, v in (c1.get("cpu") or {}).items() if k.startswith("threads_")},
+                        "max_dprob": c1.get("max_dprob_gpu_vs_oracle"), "error": c1.get("error")}
+    sus = out.get("sustained")
+    if isinstance(sus, dict):
+        smi = sus.get("rocm_smi") or {}
+        c["sustained"] = {"value": sus.get("value"), "seconds": sus.get("seconds"), "W": smi.get("package_W_mean"), "MHz": smi.get("shader_MHz_mean")}
+    for k in ("host_fed_images_per_s", "two_forwards_in_flight"):
+        if isinstance(out.get(k), dict):
+            c[k] = out[k].get("value", out[k].get("error"))
+    c["extras"] = os.path.basename(EXTRAS_FILE)
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:      # never let the line outgrow the driver's reader again: drop the optional summaries, largest first
+        for k in ("kernels", "kernels_fields", "config1", "class_rows_last_layer", "sustained", "host_fed_images_per_s", "two_forwards_in_flight"):
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    if len(line) > COMPACT_LIMIT and isinstance(c.get("other_configs"), dict):
+        c["other_configs"] = {k: ({"value": v.get("value"), "frac": v.get("frac"), "passed": (v.get("parity") or {}).get("passed")} if isinstance(v, dict) else v)
+                              for k, v in c["other_configs"].items()}
+        line = json.dumps(c, separators=(",", ":"))
+    return line
+
+
+def write_extras(out):
+    """The full record next to bench.py (and under gpurun_out/ when that directory exists: it is what travels back from a GPU box)."""
+    txt = json.dumps(out)
+    for path in (EXTRAS_FILE, os.path.join(ROOT, "gpurun_out", "bench_extras.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(txt + "\n")
+        except OSError:
+            pass
 
 
 def committed_traffic():
@@ -222,6 +337,16 @@ def parity_of(np, got, ref_p, bound, extra=None, gate=None):
         par.update(extra)
     par["passed"] = bool(d <= bound and par["top1_equal_where_decided"])
     return par
+
+
+Q_REF_RATIO_LIMIT = 4.0     # tests/test_cpu_oracle.py holds the same ratio below this on the bench rows
+
+
+def vs_reference_semantics(max_dprob, ref_self_noise):
+    """A quantised file: |dp| of the engine (dequantised blocks x 16-bit activations) against the reference's own semantics (q8_0-quantised
+    activations, integer block sums), beside how far that semantics moves against ITSELF when only its f32 summation order changes."""
+    return {"max_dprob": float(f"{max_dprob:.3e}"), "ref_self_noise": float(f"{ref_self_noise:.3e}"),
+            "ratio": round(max_dprob / ref_self_noise, 2) if ref_self_noise > 0 else None, "ratio_limit": Q_REF_RATIO_LIMIT, "gated": False}
 
 
 def config1(np, torch, pkg, binding, O, device, st, stream, reps=25):
@@ -487,6 +612,15 @@ def main():
         host_feed = B * nfed / (time.perf_counter() - tf0)
         del d_u8, imgs2, probs2
 
+    # N > 1: which ranks the process group saw and the device each one ran on, so that a scaling line describes itself
+    rank_info = None
+    if dist is not None:
+        mine_ = {"rank": rank, "device": "cpu (stub)" if stub else f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine_)
+        names = sorted({g_["device"].split(" ", 1)[-1] for g_ in gathered})
+        rank_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_seen": sorted(g_["rank"] for g_ in gathered),
+                     "devices": names if len(names) == 1 else [g_["device"] for g_ in gathered]}
     failed = []                                   # parity gates that did not hold: the run exits 1 after printing the line
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -497,6 +631,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} {args.dtype} ({args.ftype} weight file), batch={B} per GPU, {S}x{S}x3 f32 HWC inputs in HBM, random-init weights in the reference's file format",
+                       "workload_short": f"{args.model} {args.dtype}, batch={B}/GPU, {S}x{S}x3 f32 HWC in HBM, random-init {args.ftype} file",
                        "graph": "every token row of every layer, as the reference builds it (vit.cpp:805-900); the engine's default leaves out the last layer's rows that cannot reach the output: class_rows_last_layer",
                        "global_batch": world * B, "parallelism": f"dp{world} (batch shards, replicated weights, 1 all-gather of probs/step)" if world > 1 else "single GPU"},
             "gflop_per_image": round(gflop, 4), "weights": args.ftype,
@@ -507,6 +642,8 @@ def main():
             "mfma_roofline_frac_whole_forward": round(value / world * gflop / 1e3 / PEAK_TFLOPS, 4),
             "library": "stub" if stub else os.path.relpath(binding.LIB_PATH, ROOT),
         }
+        if rank_info is not None:
+            out["config"]["ranks"] = rank_info
         if overrides:
             out["invalid"] = f"development overrides in the environment: {overrides}"
         if stub:
@@ -674,6 +811,8 @@ def main():
                     if ftype_name != "f16":
                         ex["ref_is"] = "the reference's block semantics: q8_0-quantised activations x the file's blocks, integer inner sums (oracle REF, quant_act = 1); reported, not gated: it is not reproducible against itself below ~5e-3 (DESIGN 7)"
                     line["parity"] = parity_of(np, got_all[rows_], rp, bnd, ex, gate)
+                    if ftype_name != "f16":      # the deviation from the reference's q8_0-activation semantics next to that semantics' own self-noise (reported, bounded by a test, not gated)
+                        line["vs_reference_semantics"] = vs_reference_semantics(line["parity"]["max_dprob_vs_ref"], ex["noise_floor"])
                     om_.close()
                 c_.close(); m_.close()
                 return line
@@ -707,12 +846,16 @@ def main():
                     if full_p is not None:      # all B images against the every-row forward of the same operand type
                         ln_["max_dprob_vs_every_row_forward"] = float(np.abs(got_ - full_p).max())
                         ln_["top1_equal_to_every_row_forward"] = bool((got_.argmax(1) == full_p.argmax(1)).all())
+                        lim = CLS_TAIL_BOUND[dn]
+                        if ln_["max_dprob_vs_every_row_forward"] > lim or not ln_["top1_equal_to_every_row_forward"]:
+                            failed.append(f"class-rows-only last layer ({dn}) differs from the every-row forward by {ln_['max_dprob_vs_every_row_forward']:.3e} (> {lim:.1e}) or in a top-1")
                     crl[dn] = ln_
                 crl["what"] = ("vitx_ctx_options::last_layer_all_rows = 0 (the library's default): attention, output projection, norm2 and MLP of the LAST layer on one row per image; "
                                "the fractions of these lines count the flops executed (6.3 % fewer for ViT-B), not the whole graph's")
                 out["class_rows_last_layer"] = crl
-            except Exception as e:
+            except Exception as e:      # this block is the only one that runs what callers get by default: a crash here fails the run
                 out["class_rows_last_layer"] = {"error": str(e)}
+                failed.append(f"class-rows-only last layer did not run: {e}")
             ctx.close()
             # (3) BASELINE.json configs 5 and 3, measured like the primary (fewer steps), each with oracle rows of its own batch
             others = {}
@@ -737,7 +880,8 @@ def main():
             out["extras_wall_s"] = round(time.perf_counter() - extras_t0, 1)
         if failed:
             out["invalid"] = "parity gate failed: " + "; ".join(failed)
-        print(json.dumps(out), flush=True)
+        write_extras(out)
+        print(compact_line(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

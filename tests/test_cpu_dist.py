@@ -86,7 +86,11 @@ def test_bench_plumbing_under_torchrun(world):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert last == lines[0] and len(last.encode()) < 8192            # the driver parses the LAST stdout line: compact, one object
+    d = json.loads(last)
+    ranks = d["config"]["ranks"]                                     # a scaling line says which ranks the process group saw
+    assert ranks["world_size"] == world and ranks["ranks_seen"] == list(range(world)) and ranks["backend"] == "gloo"
     assert d["n_gpus"] == world and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["global_batch"] == 4 * world
     assert abs(d["value"] - 4 * world * 3 / (d["ms_per_step"] * 3e-3)) <= 0.02 * d["value"]          # whole-job aggregate, not per rank
@@ -130,3 +134,35 @@ def test_bench_gate_and_roofline_arithmetic():
     assert abs(roof["avg_launch_ms"] - (3.30 - 24 * 0.005) / 24) < 1e-4 and abs(roof["avg_launch_ms_raw_event_interval"] - 3.30 / 24) < 1e-4
     assert abs(roof["achieved"] - 2.856e12 / ((3.30 - 0.12) * 1e-3) / 1e12) < 0.1 and roof["achieved"] > roof["achieved_raw_event_interval"]
     assert abs(table["attention"]["us_per_launch"] - (1.0 - 0.12) / 24 * 1e3) < 0.01 and "HIP events" in roof["clock"]
+
+
+def test_bench_last_line_is_compact():
+    """r05's final line was 28 KB and the driver recorded `parsed: null`.  compact_line() reduces a FULL record -- here
+    the committed r05 one, the very record that broke the parse -- to one json.loads-able line below 6 KiB that still carries the contract's keys,
+    `roofline`, `cpu_baseline`, every gate's verdict and one short summary per other configuration; and it can never outgrow the limit
+    (optional summaries are dropped first)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r05", "cls_tail", "boxF_57ab21f", "bench_default.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line.encode()) <= bench.COMPACT_LIMIT < 8192
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in c and c[k] == (full[k] if k != "config" else c[k]), k
+    assert "model" not in c["config"] and c["config"]["workload"].startswith("vit_base_patch16_224")
+    r = c["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] == full["roofline"]["traffic"]
+    assert c["cpu_baseline"] == full["cpu_baseline"] and c["probe_tflops"] > 1000
+    assert c["parity"]["passed"] is True and c["parity"]["bound"] > c["parity"]["max_dprob_vs_ref"] > 0
+    assert c["parity_mode"]["parity"]["passed"] is True and c["parity_mode"]["value"] == full["parity_mode"]["value"]
+    assert len(c["other_configs"]) == 3 and all("value" in v and "frac" in v and v["parity"]["passed"] for v in c["other_configs"].values())
+    # a record with absurdly many configurations still fits: the optional blocks go first
+    fat = dict(full, other_configs={f"cfg{i}": v for i in range(6) for v in full["other_configs"].values()})
+    assert len(bench.compact_line(fat).encode()) <= 8192
+    # the q4_0 deviation from the reference's own semantics beside that semantics' self-noise (item 6)
+    v = bench.vs_reference_semantics(6.6e-2, 2.3e-2)
+    assert v["ratio"] == 2.87 and v["ratio"] < v["ratio_limit"] == bench.Q_REF_RATIO_LIMIT and v["gated"] is False

@@ -49,7 +49,7 @@ template <typename T> __global__ void gather_kernel(const void *out, int epi, in
 static double gelu_ref(double x) { return 0.5 * x * (1.0 + tanh(0.79788456080286535588 * x * (1.0 + 0.044715 * x * x))); }
 
 struct Shape { const char *name; int M, N, K; int Mr = 0; };   // Mr: rows stored (0 = all M): the last row block is then an edge tile
-struct Variant { const char *name; int kind; int cfg; };   // kind 0: ring cfg, 1: ping-pong
+struct Variant { const char *name; int kind; int cfg; };   // kind 0: ring cfg, 1: ping-pong, 2: one wave per SIMD (gemm_w4.hip)
 
 template <typename T>
 static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int iters, int n_cu, bool check) {
@@ -71,7 +71,8 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
     if (v.kind == 1 && (v.cfg & (28 | 2048))) check = false;
     if (v.kind == 1 && (v.cfg & 12288)) check = true;      // ablation builds compute garbage on purpose
     const bool brief = false;
-    auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(*g_tune, dtype, epi, g, v.cfg, 0) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
+    if (v.kind == 2 && (v.cfg & (28 | 64 | 2048))) check = false;
+    auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(*g_tune, dtype, epi, g, v.cfg, 0) : v.kind == 2 ? launch_gemm_w4(dtype, epi, g, n_cu, 0, v.cfg) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
 
     // ---- check first (on a fresh output buffer): 4096 sampled outputs incl. the corners of the first and last tile
     char verdict[96] = "unchecked";
@@ -179,7 +180,8 @@ int main(int argc, char **argv) {
     };
     // kind 1 = ping-pong kernel, cfg = its FLAGS (gemm_pp.hip; non-zero builds exist under -DVITX_LAB only, which this tool is compiled with)
     const Variant variants[] = {{"ring945", 0, 945}, {"pp", 1, 0},  {"pp_noprio", 1, 1}, {"pp_nodma", 1, 4}, {"pp_noread", 1, 8}, {"pp_mfmaonly", 1, 12},
-                                {"pp_nomfma", 1, 16}, {"pp_stamp", 1, 32}, {"pp_drain", 1, 512}, {"pp_noepi", 1, 2048}};
+                                {"pp_nomfma", 1, 16}, {"pp_stamp", 1, 32}, {"pp_drain", 1, 512}, {"pp_noepi", 1, 2048},
+                                {"w4", 2, 0}, {"w4_nodma", 2, 4}, {"w4_noread", 2, 8}, {"w4_mfmaonly", 2, 12}, {"w4_nomfma", 2, 16}, {"w4_nobar", 2, 64}, {"w4_bare", 2, 76}, {"w4_noepi", 2, 2048}};
     for (const Shape &sh : shapes)
         for (const Variant &v : variants) {
             int epis[4] = {EPI_BIAS, -1, -1, -1};
@@ -188,7 +190,8 @@ int main(int argc, char **argv) {
             if (!strcmp(sh.name, "tiny") || !strcmp(sh.name, "edge")) { epis[1] = EPI_BIAS_GELU; epis[2] = EPI_BIAS_RESID; epis[3] = EPI_BIAS_F32; }
             if (!strcmp(sh.name, "ragged") || !strcmp(sh.name, "k256") || !strcmp(sh.name, "k128")) epis[1] = EPI_BIAS_GELU;
             for (int e = 0; e < 4; ++e) {
-                if (epis[e] < 0 || (v.kind == 1 && v.cfg && epis[e] != EPI_BIAS)) continue;
+                if (epis[e] < 0 || (v.kind >= 1 && v.cfg && epis[e] != EPI_BIAS)) continue;
+                if (v.kind == 2 && epis[e] != EPI_BIAS && epis[e] != EPI_BIAS_GELU) continue;
                 if (v.kind == 0 && sh.Mr) continue;
                 for (int dtype = 0; dtype < 2; ++dtype) {
                     if (dtype == 0 && strcmp(sh.name, "tiny") && strcmp(sh.name, "edge") && strcmp(sh.name, "qkv") && strcmp(sh.name, "ragged") && strcmp(sh.name, "k256")) continue;    // f16: correctness shapes + one big one

@@ -21,11 +21,15 @@ template <typename T> __device__ __forceinline__ typename Pair<T>::v2 hilo_lo_pa
     return round_pair<T>((v0 - (float)hi[0]) * kHiLoScale, (v1 - (float)hi[1]) * kHiLoScale);
 }
 
+// How an epilogue takes an accumulator tile: plain values (every kernel but one), or -- gemm_w4.hip -- tiles pinned to physical accumulator
+// registers behind inline assembly, copied to VGPRs at the point of use (AccPhys there).  idx = 8 * (16-row block) + column tile + idx0.
+struct AccPlain { static __device__ __forceinline__ f32x4 get(const f32x4 &a, int) { return a; } };
+
 // acc[t][u]: tile rows row0 + 16 t (row0 already includes l15), columns col0 + 16 u .. + 3 (col0 already includes 4 g4).
 // FULL: the whole workgroup tile is inside [0, M_real) x [0, N) -- no bounds checks, vector bias loads.  Otherwise every element is
 // checked on its own (N need not be a multiple of 4: the classifier head has as many columns as the model has classes).
-template <typename T, int EPI, int TM, int TN, bool FULL>
-__device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][TN], int row0, int col0) {
+template <typename T, int EPI, int TM, int TN, bool FULL, typename ACC = AccPlain>
+__device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][TN], int row0, int col0, int idx0 = 0) {
     typedef typename Elem<T>::v4 v4;
     typedef typename Pair<T>::v2 v2;
 #pragma unroll
@@ -45,7 +49,7 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][T
             for (int t = 0; t < TM; ++t) {
                 const int row = row0 + t * 16;
                 if (!FULL && row >= g.M_real) continue;
-                const f32x4 v = acc[t][u] + bv;
+                const f32x4 v = ACC::get(acc[t][u], t * 8 + u + idx0) + bv;
                 v2 p0, p1;
                 if constexpr (EPI == EPI_BIAS_GELU) { p0 = gelu_out_pair<T>(v[0], v[1]); p1 = gelu_out_pair<T>(v[2], v[3]); }
                 else { p0 = round_pair<T>(v[0], v[1]); p1 = round_pair<T>(v[2], v[3]); }
@@ -103,7 +107,7 @@ __device__ __forceinline__ void epilogue16(const GemmArgs &g, f32x4 (&acc)[TM][T
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 if (!FULL && row0 + t * 16 >= g.M_real) continue;
-                f32x4 r = acc[t][u] + bv;
+                f32x4 r = ACC::get(acc[t][u], t * 8 + u + idx0) + bv;
                 if constexpr (EPI == EPI_BIAS_RESID || EPI == EPI_PATCH) r = r + add[t];      // (acc + bias) + x: the reference's order (vit.cpp:868-873)
                 if (vec) *(f32x4 *)o[t] = r;
                 else {
@@ -143,8 +147,8 @@ __device__ __forceinline__ void pp_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t ro
 // The wave's block is (NB * 32) rows x 64 columns: acc[2 NB][4].  bq[u] = bias of columns 16 u + 4 g4 .. + 3.
 // voff = this lane's byte offset in row layout (row lane >> 3 of the wave's block, 16-byte piece lane & 7), soff = tile origin,
 // soff8 = 8 rows, all in bytes of the output type; ro = buffer resource of the output matrix.
-template <typename T, int EPI, int NB, int AUX = 0>
-__device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const f32x4 (&bq)[4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane, int hilo_soff = 0) {
+template <typename T, int EPI, int NB, int AUX = 0, typename ACC = AccPlain>
+__device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const f32x4 (&bq)[4], __amdgpu_buffer_rsrc_t ro, char *patch, int voff, int soff, int soff8, int lane, int hilo_soff = 0, int idx0 = 0) {
     // The 4 KiB patch is used as TWO halves of 16 rows x 128 B (r03): block b + 1 is converted and written into the other half between the
     // issue of block b's read-back and its stores, so the LDS write -> read round trip and the stores' issue time hide under the next
     // block's VALU work instead of serialising once per block.  (The LDS executes a wave's operations in issue order; the compiler-level
@@ -163,7 +167,7 @@ __device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const
             char *pb = patch + (q & 1) * 2048 + wr_row;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const f32x4 v = acc[b][u] + bq[u];
+                const f32x4 v = ACC::get(acc[b][u], b * 8 + u + idx0) + bq[u];
                 v2 p0, p1;
                 if constexpr (EPI == EPI_BIAS_GELU) { p0 = gelu_out_pair<T>(v[0], v[1]); p1 = gelu_out_pair<T>(v[2], v[3]); }
                 else { p0 = round_pair<T>(v[0], v[1]); p1 = round_pair<T>(v[2], v[3]); }
@@ -197,7 +201,7 @@ __device__ __forceinline__ void epilogue16_staged(f32x4 (&acc)[2 * NB][4], const
             char *pb = patch + (c & 1) * 2048 + wr_row;
 #pragma unroll
             for (int uu = 0; uu < 2; ++uu)          // columns (2j + uu) * 16 + 4 g4 of the wave = (uu * 16 + 4 g4) of this 32-column half: slot 4 uu + g4
-                *(f32x4 *)(pb + (((4 * uu + g4) * 16) ^ x16)) = acc[b][2 * j + uu] + bq[2 * j + uu];
+                *(f32x4 *)(pb + (((4 * uu + g4) * 16) ^ x16)) = ACC::get(acc[b][2 * j + uu], b * 8 + 2 * j + uu + idx0) + bq[2 * j + uu];
             pp_lds_fence();
         };
         if constexpr (EPI == EPI_BIAS_RESID) load_res(0, res[0]);
