@@ -145,8 +145,9 @@ typedef struct vitx_ctx_options {
                                  attention kernels) instead of the parity mode's f32-grade products (two fp16 planes, three MFMAs per product) */
     int32_t last_layer_all_rows; /* 1 = the last encoder layer computes every token row, as the reference graph does (vit.cpp:805-900 for il = L - 1).
                                  Default 0: past its qkv projection the last layer of a classifier carries only the class-token row of each image -- the only
-                                 row vit.cpp:910-911 reads, and no other row can reach it (rows meet only through k and v inside the attention).  Same
-                                 probabilities; 0.76 of one layer's work is not done (ViT-B: 6.3 % of the forward's flops).  ViTSTR contexts and contexts with a
+                                 row vit.cpp:910-911 reads, and no other row can reach it (rows meet only through k and v inside the attention).  The
+                                 probabilities are equal within the operand type's rounding (measured on 256 images: 1.1e-3 bf16, 3.0e-4 F16, top-1 equal), not
+                                 bit for bit; 0.76 of one layer's work is not done (ViT-B: 6.3 % of the forward's flops).  ViTSTR contexts and contexts with a
                                  residual-stream trace always compute every row. */
 } vitx_ctx_options;
 #define VITX_LN_TEST_KEY 0x7e570000
@@ -322,7 +323,9 @@ int vitx_op_softmax_dt(int dtype, const void *d_logits, void *d_probs, int rows,
 /* ---- residual-stream trace (parity localisation) ------------------------------ */
 /* After vitx_trace_enable(ctx, ids, n) every forward also copies the f32 residual stream X of images ids[0..n) -- after the
  * patch embedding and after each encoder layer -- into a device buffer; vitx_trace_read() synchronises and returns it as
- * [L + 1][n][tokens][hidden] f32 (vit.cpp:797 and :900: the tensor `cur` carries between blocks).  n = 0 disables. */
+ * [L + 1][n][tokens][hidden] f32 (vit.cpp:797 and :900: the tensor `cur` carries between blocks).  n = 0 disables.
+ * A traced context evaluates EVERY row of the last layer (as with last_layer_all_rows = 1): its probabilities are those of the whole graph and
+ * can differ from the same context's untraced forward by the operand type's rounding (bf16 about 1e-3). */
 int vitx_trace_enable(vitx_ctx *c, const int32_t *image_ids, int n);
 int vitx_trace_read(vitx_ctx *c, float *out, size_t n_floats);
 

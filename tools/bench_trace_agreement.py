@@ -12,6 +12,10 @@ from timeline import classify
 
 db, line = sys.argv[1], sys.argv[2]
 d = json.loads(open(line).read().strip().splitlines()[-1])
+if "kernel_breakdown" not in d:      # r06: the last stdout line is the compact one; the per-kernel table is in the full record the same run wrote next to bench.py
+    import os
+    full = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), d.get("extras", "bench_extras.json"))
+    d = json.load(open(full))
 rows = sqlite3.connect(db).execute("select name, queue_id, start, end from kernels order by start").fetchall()
 ks, resid_n = [], defaultdict(int)
 for name, q, s, e in rows:

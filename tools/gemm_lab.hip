@@ -49,7 +49,7 @@ template <typename T> __global__ void gather_kernel(const void *out, int epi, in
 static double gelu_ref(double x) { return 0.5 * x * (1.0 + tanh(0.79788456080286535588 * x * (1.0 + 0.044715 * x * x))); }
 
 struct Shape { const char *name; int M, N, K; int Mr = 0; };   // Mr: rows stored (0 = all M): the last row block is then an edge tile
-struct Variant { const char *name; int kind; int cfg; };   // kind 0: ring cfg, 1: ping-pong, 2: one wave per SIMD (gemm_w4.hip)
+struct Variant { const char *name; int kind; int cfg; };   // kind 0: ring cfg, 1: ping-pong, 2 / 3: free-running kernels with 4 / 8 waves (gemm_w4.hip)
 
 template <typename T>
 static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int iters, int n_cu, bool check) {
@@ -68,11 +68,13 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
     if (const char *e = getenv("LAB_GROUP_M")) g.group_m = atoi(e);
     unsigned *tl = nullptr;
     if (v.kind == 1 && (v.cfg & 32)) { CK(hipMalloc(&tl, 256 * 8 * 64 * 4)); CK(hipMemset(tl, 0, 256 * 8 * 64 * 4)); g.pos = (const float *)tl; }
+    long long *clk = nullptr;      // clock probe of the free-running kernels (and pp_clock): per workgroup {shader cycles, 100 MHz ticks, tiles, K-tiles per tile}
+    if (v.kind >= 2 || (v.kind == 1 && v.cfg == 4096)) { CK(hipMalloc(&clk, 256 * 4 * 8)); CK(hipMemset(clk, 0, 256 * 4 * 8)); g.pos = (const float *)clk; }
     if (v.kind == 1 && (v.cfg & (28 | 2048))) check = false;
-    if (v.kind == 1 && (v.cfg & 12288)) check = true;      // ablation builds compute garbage on purpose
+    if (v.kind == 1 && v.cfg == 4096) check = true;
     const bool brief = false;
-    if (v.kind == 2 && (v.cfg & (28 | 64 | 2048))) check = false;
-    auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(*g_tune, dtype, epi, g, v.cfg, 0) : v.kind == 2 ? launch_gemm_w4(dtype, epi, g, n_cu, 0, v.cfg) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
+    if (v.kind >= 2 && (v.cfg & (28 | 64 | 2048))) check = false;
+    auto launch = [&]() -> hipError_t { return v.kind == 0 ? launch_gemm_ring(*g_tune, dtype, epi, g, v.cfg, 0) : v.kind >= 2 ? launch_gemm_w4(dtype, epi, g, n_cu, 0, v.cfg, false, v.kind == 2 ? 4 : 8) : launch_gemm_pp(dtype, epi, g, n_cu, 0, v.cfg); };
 
     // ---- check first (on a fresh output buffer): 4096 sampled outputs incl. the corners of the first and last tile
     char verdict[96] = "unchecked";
@@ -133,6 +135,14 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
     printf("%-7s M=%-6d N=%-5d K=%-5d %-9s epi=%d %s  mean %9.1f us  best %9.1f us  %7.1f TF/s  %s\n", sh.name, M, N, K, v.name, epi, dtype == DT_F16 ? "f16 " : "bf16",
            us, best * 1e3, tf, verdict);
     fflush(stdout);
+    if (clk) {
+        std::vector<long long> h(256 * 4);
+        CK(hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost));
+        double cyc = 0, tick = 0, kt = 0; int nb = 0;
+        for (int b = 0; b < 256; ++b) if (h[b * 4 + 2] > 0) { cyc += (double)h[b * 4]; tick += (double)h[b * 4 + 1]; kt += (double)h[b * 4 + 2] * h[b * 4 + 3]; ++nb; }
+        if (nb) printf("   clock: %d workgroups, mean %.0f shader cycles in %.2f us = %.0f MHz effective; %.0f cycles per K-tile (epilogues included)\n", nb, cyc / nb, tick / nb / 100.0, cyc / tick * 100.0, cyc / kt);
+        CK(hipFree(clk));
+    }
     if (tl) {      // timeline: stamps after each barrier (2 per phase, 16 phases = K-tiles 4..7 of the first tile), waves 0 and 4 of a few workgroups
         std::vector<unsigned> h(256 * 8 * 64);
         CK(hipMemcpy(h.data(), tl, h.size() * 4, hipMemcpyDeviceToHost));
@@ -180,8 +190,9 @@ int main(int argc, char **argv) {
     };
     // kind 1 = ping-pong kernel, cfg = its FLAGS (gemm_pp.hip; non-zero builds exist under -DVITX_LAB only, which this tool is compiled with)
     const Variant variants[] = {{"ring945", 0, 945}, {"pp", 1, 0},  {"pp_noprio", 1, 1}, {"pp_nodma", 1, 4}, {"pp_noread", 1, 8}, {"pp_mfmaonly", 1, 12},
-                                {"pp_nomfma", 1, 16}, {"pp_stamp", 1, 32}, {"pp_drain", 1, 512}, {"pp_noepi", 1, 2048},
-                                {"w4", 2, 0}, {"w4_nodma", 2, 4}, {"w4_noread", 2, 8}, {"w4_mfmaonly", 2, 12}, {"w4_nomfma", 2, 16}, {"w4_nobar", 2, 64}, {"w4_bare", 2, 76}, {"w4_noepi", 2, 2048}};
+                                {"pp_nomfma", 1, 16}, {"pp_stamp", 1, 32}, {"pp_drain", 1, 512}, {"pp_noepi", 1, 2048}, {"pp_clock", 1, 4096},
+                                {"w4", 2, 0}, {"w4_nodma", 2, 4}, {"w4_noread", 2, 8}, {"w4_mfmaonly", 2, 12}, {"w4_nomfma", 2, 16}, {"w4_nobar", 2, 64}, {"w4_bare", 2, 76}, {"w4_noepi", 2, 2048},
+                                {"w8", 3, 0}, {"w8_nodma", 3, 4}, {"w8_noread", 3, 8}, {"w8_mfmaonly", 3, 12}, {"w8_nomfma", 3, 16}, {"w8_nobar", 3, 64}, {"w8_bare", 3, 76}, {"w8_noepi", 3, 2048}};
     for (const Shape &sh : shapes)
         for (const Variant &v : variants) {
             int epis[4] = {EPI_BIAS, -1, -1, -1};
@@ -191,7 +202,7 @@ int main(int argc, char **argv) {
             if (!strcmp(sh.name, "ragged") || !strcmp(sh.name, "k256") || !strcmp(sh.name, "k128")) epis[1] = EPI_BIAS_GELU;
             for (int e = 0; e < 4; ++e) {
                 if (epis[e] < 0 || (v.kind >= 1 && v.cfg && epis[e] != EPI_BIAS)) continue;
-                if (v.kind == 2 && epis[e] != EPI_BIAS && epis[e] != EPI_BIAS_GELU) continue;
+                if (v.kind >= 2 && epis[e] != EPI_BIAS && epis[e] != EPI_BIAS_GELU) continue;
                 if (v.kind == 0 && sh.Mr) continue;
                 for (int dtype = 0; dtype < 2; ++dtype) {
                     if (dtype == 0 && strcmp(sh.name, "tiny") && strcmp(sh.name, "edge") && strcmp(sh.name, "qkv") && strcmp(sh.name, "ragged") && strcmp(sh.name, "k256")) continue;    // f16: correctness shapes + one big one

@@ -6,6 +6,7 @@ tag=${1:-rXX}
 cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag; mkdir -p $out
 python bench.py > $out/bench_default.json 2> $out/bench_default.err          # exactly what the driver runs
+cp bench_extras.json $out/bench_default_extras.json 2>/dev/null              # the full record behind the compact line
 python bench.py --steps 30 --warmup 10 > $out/bench_bf16.json 2> $out/bench_bf16.err
 python bench.py --steps 30 --warmup 10 --dtype f16 --no-cpu-baseline --no-extras > $out/bench_f16.json 2> $out/bench_f16.err
 python bench.py --steps 30 --warmup 10 --ftype q4_0 --no-extras > $out/bench_q4_0.json 2> $out/bench_q4_0.err

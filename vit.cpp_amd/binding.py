@@ -262,6 +262,11 @@ class Context:
             if k not in dict(CtxOptions._fields_) or k == "struct_size":
                 raise TypeError(f"unknown context option {k!r}")
             setattr(opt, k, int(v))
+        # struct_size = the smallest prefix that covers every field that is set: a library that predates a trailing field (tools/ab_libs.py loads
+        # older builds through VITX_LIB) rejects a struct_size above its own sizeof(vitx_ctx_options) -- zero trailing fields are its defaults anyway
+        names = [f for f, _ in CtxOptions._fields_]
+        last = max([i for i, f in enumerate(names) if f != "struct_size" and getattr(opt, f) != 0] + [names.index("f16_fast_attention")])
+        opt.struct_size = 4 * (last + 1)
         check(lib().vitx_ctx_create_ex(model._h, device, max_batch, dtype, C.byref(opt), C.byref(self._h)), "vitx_ctx_create_ex")
 
     def close(self):

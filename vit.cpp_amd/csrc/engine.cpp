@@ -992,8 +992,9 @@ int vitx_profile_bracket_us(vitx_ctx *c, double *bracket_us) {
     long long *d_st = nullptr; hipEvent_t ev[2 * NB];
     HIP_TRY(hipMalloc((void **)&d_st, sizeof(long long) * 2 * NB));
     int made = 0; hipError_t e = hipSuccess;
-    for (; made < 2 * NB && e == hipSuccess; ++made) e = hipEventCreate(&ev[made]);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    while (made < 2 * NB) { if ((e = hipEventCreate(&ev[made])) != hipSuccess) break; ++made; }      // `made` counts the handles that exist
+    // nothing else of this device may be in flight (another slice stream's forward would stretch the brackets): the whole device, not only c->stream
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     for (int i = 0; i < NB && e == hipSuccess; ++i) {
         e = hipEventRecord(ev[2 * i], c->stream);
         if (e == hipSuccess) e = launch_spin_stamp(20, d_st + 2 * i, c->stream);

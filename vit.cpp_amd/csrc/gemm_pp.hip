@@ -349,6 +349,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
         }
     };
     if (my_tiles <= 0) return;
+#ifdef VITX_LAB
+    const long long lab_c0 = __builtin_readcyclecounter(), lab_r0 = __builtin_amdgcn_s_memrealtime();      // laboratory clock probe (FLAGS 4096)
+#endif
 
     // ---- consumer side of a LayerNorm-fusing GEMM (GemmArgs::fix): A = that GEMM's normalised rows.  Row blocks it left to the fix-up
     // (a peer workgroup did not answer in time) are recomputed from X HERE, by every workgroup for the row blocks of ITS OWN tiles, before
@@ -562,6 +565,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(PP_MAX_VGPR)
     if (wr == 0) pp_barrier();
     pp_wait_vmcnt<0>();                             // the trailing (unused) stages must land before the LDS allocation is released
     if constexpr ((FLAGS & 32) != 0) ((unsigned *)g.pos)[((size_t)bid * 8 + wave) * 64 + lane] = stamps;
+#ifdef VITX_LAB
+    if constexpr ((FLAGS & 4096) != 0) {
+        if (g.pos && tid == 0) {
+            long long *o = (long long *)g.pos + (size_t)bid * 4;
+            o[0] = __builtin_readcyclecounter() - lab_c0; o[1] = __builtin_amdgcn_s_memrealtime() - lab_r0; o[2] = my_tiles; o[3] = g.K / BK;
+        }
+    }
+#endif
 #undef PP_PHASE
 }
 
@@ -620,6 +631,7 @@ static hipError_t launch_pp_t(int epi, const GemmArgs &a, int n_cu, hipStream_t 
         case 32: return launch_pp_inst<T, EPI_BIAS, 32>(a, n_cu, stream, prepare);
         case 512: return launch_pp_inst<T, EPI_BIAS, 512>(a, n_cu, stream, prepare);
         case 2048: return launch_pp_inst<T, EPI_BIAS, 2048>(a, n_cu, stream, prepare);
+        case 4096: return launch_pp_inst<T, EPI_BIAS, 4096>(a, n_cu, stream, prepare);
         default: return hipErrorInvalidValue;
         }
     }
