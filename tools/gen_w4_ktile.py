@@ -3,7 +3,7 @@
 
 Why assembly: hipcc 7.2 cannot hold 64 accumulator tiles (256 AGPRs) + two fragment sets in place through a software-pipelined loop -- the
 C++ build of the same schedule moved half the accumulators between VGPRs and AGPRs around every MFMA and spilled ~100 registers
-(profiles/r06/w4_hipcc_attempt.txt).  The register ALLOCATION stays with the compiler (every register is an asm operand); only the
+(profiles/r06/gemm_structures.md).  The register ALLOCATION stays with the compiler (every register is an asm operand); only the
 instruction order and the wait counts inside a K-tile are fixed here.
 
 One K-tile (BK = 64) of one wave = 128 v_mfma_f32_16x16x32 on an 8 x 8 grid of accumulator tiles:

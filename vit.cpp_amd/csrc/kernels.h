@@ -158,8 +158,8 @@ hipError_t launch_gemm_ring(const Tuning &t, int dtype, int epi, const GemmArgs 
 bool gemm_ring_supports(const GemmArgs &a, int cfg);
 hipError_t launch_gemm_pp(int dtype, int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags = 0, bool prepare = false);
 bool gemm_pp_supports(const GemmArgs &a);
-// free-running wide kernels (gemm_w4.hip), waves = 8: two waves per SIMD, 128 x 64 of C per wave; 4 (laboratory build only): one per SIMD,
-// 128 x 128 per wave.  EPI_BIAS, EPI_BIAS_GELU; same bits as the other families
+// free-running wide kernels (gemm_w4.hip; LABORATORY BUILD ONLY: tools/Makefile), waves = 8: two waves per SIMD, 128 x 64 of C per wave; 4: one
+// per SIMD, 128 x 128 per wave.  EPI_BIAS, EPI_BIAS_GELU; same bits as the other families
 hipError_t launch_gemm_w4(int dtype, int epi, const GemmArgs &a, int n_cu, hipStream_t stream, int flags = 0, bool prepare = false, int waves = 8);
 bool gemm_w4_supports(const GemmArgs &a);
 

@@ -1466,7 +1466,9 @@ static hipError_t prepare_device_kernels(const Tuning &t) {
         for (int epi = 0; epi <= EPI_BIAS_HILO; ++epi) {
             for (int cfg : {945, 445, 245, 122}) if ((e = launch_gemm_ring(t, dt, epi, none, cfg, nullptr, true)) != hipSuccess) return e;
             if ((e = launch_gemm_pp(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
-            if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU) && (e = launch_gemm_w4(dt, epi, none, t.n_cu, nullptr, 0, true)) != hipSuccess) return e;
+#ifdef VITX_LAB
+            for (int nw : {4, 8}) if ((epi == EPI_BIAS || epi == EPI_BIAS_GELU) && (e = launch_gemm_w4(dt, epi, none, t.n_cu, nullptr, 0, true, nw)) != hipSuccess) return e;
+#endif
             if ((e = (dt == DT_F16 ? launch_gemm_t<_Float16, true>(epi, none, nullptr, true) : launch_gemm_t<__bf16, true>(epi, none, nullptr, true))) != hipSuccess) return e;
         }
         if (dt == 0 && (e = launch_patch_embed(0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, true)) != hipSuccess) return e;
