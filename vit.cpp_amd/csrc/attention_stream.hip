@@ -55,7 +55,8 @@ constexpr int KB = CK * 128;         // bytes of one 64-row plane image (K or V 
 #define AS_CLAIM 1
 #endif
 #ifndef AP_DROP
-#define AP_DROP 0         // numerics experiment (r04 verdict item 3; profiles/r05/precise_attention_dropped_terms.txt): 1 = no k_lo . q_hi products, 2 = no P . v_lo products
+#define AP_DROP 0         // numerics experiment (r04 verdict item 3; profiles/r05/precise_attention_dropped_terms.txt, r06: profiles/r06/precise_attention_planes.txt): 1 = no k_lo . q_hi products, 2 = no P . v_lo products,
+                          // 4 = no k_hi . q_lo products.  r06: the lo plane of an operand whose products are dropped is not FETCHED either (attention_precise_kernel: a zero-length buffer descriptor returns zeros and fetches nothing)
 #endif
 #ifndef AP_K2
 #define AP_K2 1           // K fragments of both 16-key tiles of a 32-key step in flight (16 more registers, still no spill): F16 forward 11.02 -> 10.94 ms, same bits (profiles/r05/ab_precise_k2.txt)
@@ -554,6 +555,10 @@ __global__ __launch_bounds__(1024, 4) void attention_precise_kernel(const _Float
 
     // ---- LDS-DMA: this wave moves 1 KiB of ONE plane of every chunk: pieces (wave & 7) * 64 + lane of the 512 a plane image has
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(qkv + ((wave >> 3) ? lo_off : 0)), 0, (int)plane_bytes, 0x00020000);
+    // AP_DROP: the waves that move the lo plane (8..15) fetch nothing for an operand whose lo products are not formed -- a descriptor of zero records:
+    // every lane is out of range, the buffer unit writes zeros and reads no memory, and the vmcnt schedule keeps its shape
+    const bool lo_wave = (wave >> 3) != 0;
+    const bool skip_k = (AP_DROP & 1) && lo_wave, skip_v = (AP_DROP & 2) && lo_wave, skip_q = (AP_DROP & 4) && lo_wave;
     int koff, voff;
     {
         const int piece = tid & 511;
@@ -574,18 +579,21 @@ __global__ __launch_bounds__(1024, 4) void attention_precise_kernel(const _Float
     auto tail_end = [&](unsigned jb) -> int { const unsigned end = jb + tail_bytes; return (int)(end < plane_bytes ? end : plane_bytes); };     // (the descriptor itself is built at the use: a lambda RETURNING one makes hipcc 7.2 drop the kernel's host-side instantiation)
     auto stage_ring = [&](unsigned jb, int s) {          // chunk s of the item at byte offset jb: 0..3 = K, 4..7 = V
         const int so = __builtin_amdgcn_readfirstlane((int)(jb + (unsigned)((s & 3) * CK * row_bytes + (s < 4 ? D * 2 : 2 * D * 2))));
-        if ((s & 3) == 3) {
-            __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)plane_ptr, 0, tail_end(jb), 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, LPTR(smem + QB + ring_in * SLOT + dst_w), 16, s < 4 ? koff : voff, so, 0, AP_AUX);
-        } else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(smem + QB + ring_in * SLOT + dst_w), 16, s < 4 ? koff : voff, so, 0, AP_AUX);
+        const bool skip = AP_DROP && (s < 4 ? skip_k : skip_v);
+        {
+            __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)plane_ptr, 0, skip ? 0 : ((s & 3) == 3 ? tail_end(jb) : (int)plane_bytes), 0x00020000);
+            if (AP_DROP || (s & 3) == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, LPTR(smem + QB + ring_in * SLOT + dst_w), 16, s < 4 ? koff : voff, so, 0, AP_AUX);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(smem + QB + ring_in * SLOT + dst_w), 16, s < 4 ? koff : voff, so, 0, AP_AUX);
+        }
         ring_in = ring_in == NSL - 1 ? 0 : ring_in + 1;
     };
     auto stage_q = [&](unsigned jb, int q) {
         const int so = __builtin_amdgcn_readfirstlane((int)(jb + (unsigned)(q * CK * row_bytes)));
-        if (q == 3) {
-            __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)plane_ptr, 0, tail_end(jb), 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, LPTR(smem + q * SLOT + dst_w), 16, koff, so, 0, AP_AUX);
-        } else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(smem + q * SLOT + dst_w), 16, koff, so, 0, AP_AUX);
+        {
+            __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)plane_ptr, 0, (AP_DROP && skip_q) ? 0 : (q == 3 ? tail_end(jb) : (int)plane_bytes), 0x00020000);
+            if (AP_DROP || q == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, LPTR(smem + q * SLOT + dst_w), 16, koff, so, 0, AP_AUX);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LPTR(smem + q * SLOT + dst_w), 16, koff, so, 0, AP_AUX);
+        }
     };
 
     // ---- fragment addresses inside a chunk (attention_stream_kernel): K / Q tile t (16 rows) = parity (t & 1) base + (t >> 1) * 4096;
@@ -626,8 +634,10 @@ __global__ __launch_bounds__(1024, 4) void attention_precise_kernel(const _Float
         f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f}, c = {0.0f, 0.0f, 0.0f, 0.0f};
         a = Elem<T>::mfma16(k0, qh[0], a);
         a = Elem<T>::mfma16(k1, qh[1], a);
-        c = Elem<T>::mfma16(k0, ql[0], c);
-        c = Elem<T>::mfma16(k1, ql[1], c);
+        if constexpr ((AP_DROP & 4) == 0) {
+            c = Elem<T>::mfma16(k0, ql[0], c);
+            c = Elem<T>::mfma16(k1, ql[1], c);
+        }
         if constexpr ((AP_DROP & 1) == 0) {
             c = Elem<T>::mfma16(l0, qh[0], c);
             c = Elem<T>::mfma16(l1, qh[1], c);
