@@ -181,6 +181,31 @@ def test_q8_0_activation_semantics_are_not_reproducible_to_1e3(pkg, oracle, tmp_
     assert to_dequantised < 4 * noise_q          # the two semantics are as far apart as the reference is from itself
 
 
+def test_q4_0_bench_rows_distance_to_reference_semantics_is_bounded(pkg, oracle):
+    """config 5 is gated on the dequantised-weight oracle; the distance to the REFERENCE's own semantics (q8_0-quantised
+    activations x the file's blocks) is reported in the bench line as `vs_reference_semantics = {max_dprob, ref_self_noise, ratio}`.  This pins the
+    ratio on the six rows bench.py checks of its q4_0 batch (ViT-B/16, head x8, the bench's seed): the engine's arithmetic there IS the
+    oracle's quant_act = 0 mode up to 1e-3 (the F16 gate of that configuration), so the oracle can stand in for it on the CPU -- the ratio must
+    stay below bench.Q_REF_RATIO_LIMIT (measured: 2.79 here, 2.74 / 2.89 by the engine on the GPU)."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    path = pkg.synth.cached_synthetic("vit_base_patch16_224", ftype=2, head_scale=8.0)
+    g = torch.Generator(device="cpu").manual_seed(4321)                       # bench.py's batch, rank 0
+    u8 = torch.randint(0, 256, (256, 224, 224, 3), generator=g, dtype=torch.uint8)
+    rows = [0, 1, 102, 103, 254, 255]                                         # both ends + both sides of the sub-batch boundary (103 | 153)
+    imgs = ((u8[rows].float() - torch.tensor(pkg.synth.IMAGENET_MEAN)) / torch.tensor(pkg.synth.IMAGENET_STD)).contiguous().numpy()
+    om = oracle.OracleModel(path)
+    ref = om.forward(imgs, oracle.REF)[1]
+    self_noise = float(np.abs(om.forward(imgs, dataclasses.replace(oracle.REF, dot_exact=1))[1] - ref).max())
+    engine_like = float(np.abs(om.forward(imgs, dataclasses.replace(oracle.REF, quant_act=0))[1] - ref).max())
+    v = bench.vs_reference_semantics(engine_like, self_noise)
+    print("q4_0 bench rows: dequantised-weight semantics vs reference semantics %.3e, reference self-noise %.3e, ratio %.2f" % (engine_like, self_noise, v["ratio"]))
+    assert self_noise > 5e-3                                                  # the reference's block semantics is not reproducible against itself at 1e-3
+    assert v["ratio"] < bench.Q_REF_RATIO_LIMIT == 4.0
+
+
 @pytest.mark.parametrize("ftype", [2, 3, 6, 7, 8])
 def test_oracle_quantised_weights(pkg, oracle, ftype, tmp_path):
     """q4_0/q4_1/q5_0/q5_1/q8_0 files load and run with ggml's q8 activation quantisation; results stay close to f16."""
