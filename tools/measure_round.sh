@@ -7,11 +7,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag; mkdir -p $out
 python bench.py > $out/bench_default.json 2> $out/bench_default.err          # exactly what the driver runs
 cp bench_extras.json $out/bench_default_extras.json 2>/dev/null              # the full record behind the compact line
-python bench.py --steps 30 --warmup 10 > $out/bench_bf16.json 2> $out/bench_bf16.err
-python bench.py --steps 30 --warmup 10 --dtype f16 --no-cpu-baseline --no-extras > $out/bench_f16.json 2> $out/bench_f16.err
-python bench.py --steps 30 --warmup 10 --ftype q4_0 --no-extras > $out/bench_q4_0.json 2> $out/bench_q4_0.err
-python bench.py --steps 20 --warmup 5 --model vit_large_patch16_384 --batch 128 --no-cpu-baseline --no-extras > $out/bench_large384.json 2> $out/bench_large384.err
-cat $out/bench_bf16.json $out/bench_f16.json $out/bench_q4_0.json $out/bench_large384.json > $out/bench.jsonl
+# (r06: ONE bench run per round -- the default line carries the F16 mode, the q4_0 file and ViT-L/384 as `parity_mode` / `other_configs`; the full record is bench_default_extras.json)
 export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$out/prof -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 5 bf16 profile=1,last_layer_all_rows=1 > $R/$out/prof.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_HIT_sum -d $R/$out/pmc1 -o fwd -- python $R/tools/prof_forward.py vit_base_patch16_224 256 2 bf16 profile=1,last_layer_all_rows=1 > $R/$out/pmc1.log 2>&1 )
@@ -28,7 +24,8 @@ for ft in f16 q4_0; do for b in 1 8 32 64; do TF_FTYPE=$ft python tools/time_fwd
 find $out -name "*.db" -size +20M -delete
 python - <<PY
 import json
-for l in open("$out/bench.jsonl"):
-    d = json.loads(l); print(d["config"]["workload"][:60], d["value"], d["ms_per_step"], d.get("roofline", {}).get("frac"))
+d = json.loads(open("$out/bench_default.json").read().strip().splitlines()[-1])
+print(len(json.dumps(d)), "bytes;", d["config"]["workload"][:60], d["value"], d["ms_per_step"], d.get("roofline", {}).get("frac"), "parity_mode", d.get("parity_mode", {}).get("value"))
+for k, v in d.get("other_configs", {}).items(): print("  ", k, v.get("value"), v.get("frac"), (v.get("parity") or {}).get("passed"))
 PY
 head -14 $out/rocprofv3_summary.txt; cat $out/hbm_traffic.json | head -14; cat $out/bench_under_rocprofv3.txt
