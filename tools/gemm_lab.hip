@@ -113,6 +113,21 @@ static void run_one(const Shape &sh, const Variant &v, int epi, int dtype, int i
             }
             if (bad) snprintf(verdict, sizeof verdict, "CHECK FAILED %d/%d worst %.1f tol", bad, S, worst);
             else snprintf(verdict, sizeof verdict, "ok (worst %.2f tol)", worst);
+            // the free-running kernels claim the K order of every other family: the WHOLE output must equal the ping-pong kernel's bit for bit
+            if (!bad && v.kind >= 2 && v.cfg == 0 && out_elem == 2 && gemm_pp_supports(g)) {
+                const size_t nb = (size_t)M * N * out_elem;
+                void *out2; CK(hipMalloc(&out2, nb)); CK(hipMemset(out2, 0, nb));
+                GemmArgs g2 = g; g2.out = out2; g2.pos = nullptr;
+                if (launch_gemm_pp(dtype, epi, g2, n_cu, 0, 0) == hipSuccess) {
+                    CK(hipDeviceSynchronize());
+                    std::vector<uint16_t> a(nb / 2), b(nb / 2);
+                    CK(hipMemcpy(a.data(), out, nb, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), out2, nb, hipMemcpyDeviceToHost));
+                    size_t diff = 0; for (size_t i = 0; i < a.size(); ++i) diff += a[i] != b[i];
+                    const size_t l = strlen(verdict);
+                    if (diff) snprintf(verdict + l, sizeof verdict - l, "  BITS DIFFER from pp in %zu outputs", diff); else snprintf(verdict + l, sizeof verdict - l, "  == pp bit for bit");
+                }
+                CK(hipFree(out2));
+            }
         }
         (void)hipFree(dsm); (void)hipFree(dsn); (void)hipFree(dref); (void)hipFree(dgot); (void)hipFree(dprev);
     }
