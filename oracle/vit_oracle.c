@@ -220,7 +220,7 @@ typedef struct {
                         rounding points to reproduce, so the perf mode does not pay for a rounded exponent / GELU argument) */
     int attn_round;  /* q,k,v (and p) rounding before the attention products: 0 f32 (ggml), 1 fp16, 2 bf16 */
     int w_round;     /* extra rounding of the (already f16/f32) dense weights: 0 none, 2 bf16 */
-    int quant_act;   /* 1: with q* weights quantise activations to q8_0/q8_1 like ggml; 0: dequantised weights x act_round */
+    int quant_act;   /* 1: with q* weights quantise activations to q8_0/q8_1 like ggml; 0: dequantised weights x act_round; 2 (probe): as 1, from the act_round-rounded activation */
     int dot_exact;   /* probe: 1 = accumulate every dot product in double (measures ggml's own summation-order noise floor) */
     int attn_qk_round, attn_v_round; /* probe: override attn_round separately for q,k and for v (-1 = follow attn_round) */
 } omode;
@@ -367,6 +367,7 @@ void oracle_linear(const otensor *W, const float *bias, const float *x, float *y
         for (int m = 0; m < M; ++m) {
             const float *xm = x + (size_t)m * K; float *ym = y + (size_t)m * Nn;
             if (quant) {
+                if (md->quant_act == 2) { for (int k = 0; k < K; ++k) xr[k] = round_sel(xm[k], ar); xm = xr; }   /* probe: the blocks formed from the ROUNDED activation (what a device path that stores 16-bit activations can do) */
                 if (W->type == T_Q4_1 || W->type == T_Q5_1) quant_q8_1(xm, xq, K); else quant_q8_0(xm, xq, K);
                 const size_t rb = (size_t)(K / QK) * type_block_bytes(W->type);
                 for (int n = 0; n < Nn; ++n) { float v = dot_quant(W->type, W->raw + rb * n, xq, K); ym[n] = bias ? v + bias[n] : v; }
