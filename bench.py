@@ -62,7 +62,7 @@ def _short_parity(par):
     """The gate of one configuration in five numbers: what was measured, against what, the bound, the verdict."""
     if not isinstance(par, dict):
         return None
-    s = _pick(par, ("max_dprob_vs_ref", "bound", "passed", "noise_floor", "rows", "rows_decided", "top1_equal_where_decided", "gated_on", "unverified"))
+    s = _pick(par, ("max_dprob_vs_ref", "bound", "passed", "noise_floor", "rows", "rows_decided", "top1_equal_where_decided", "gated_on", "gate", "unverified"))
     if "gated_on" in par:
         s[par["gated_on"]] = par.get(par["gated_on"])
     for k, v in list(s.items()):
@@ -704,12 +704,12 @@ def main():
             if args.dtype == "bf16":
                 _, same_p = om.forward(cpu_imgs, O.GPU_BF16)
                 extra["max_dprob_vs_bf16_oracle"] = float(np.abs(got - same_p).max())
-                bound = max(BOUND_BF16, 10 * noise)
+                bound = max(BOUND_BF16, 10 * noise); extra["gate"] = "builder-defined: max(2e-2, 10 x noise_floor)"
             else:
                 if quant:
                     _, same_p = om.forward(cpu_imgs, dataclasses.replace(O.REF, quant_act=0))
                     extra["max_dprob_vs_dequantised_oracle"] = float(np.abs(got - same_p).max())
-                bound = max(BOUND_F16_FLOOR, 2 * noise)
+                bound = max(BOUND_F16_FLOOR, 2 * noise); extra["gate"] = "builder-defined: max(north_star's 1e-3, 2 x noise_floor)"
             out["parity"] = parity_of(np, got, ref_p, bound, extra)
             if not out["parity"]["passed"]:
                 failed.append(f"timed configuration ({args.dtype}) outside its parity bound: {out['parity']['max_dprob_vs_ref']:.3e} > {bound:.3e} or a decided top-1 differs")
@@ -784,7 +784,8 @@ def main():
                 if reuse is not None:            # the primary's rows, reference probabilities and noise floor (same images, same weight file)
                     rows_, rp, nz = reuse
                     line["parity"] = parity_of(np, got_all[rows_], rp, max(BOUND_F16_FLOOR, 2 * nz) if dtype_name == "f16" else max(BOUND_BF16, 10 * nz),
-                                               {"row_ids": rows_, "sub_batches": c_.split(batch), "noise_floor": nz})
+                                               {"row_ids": rows_, "sub_batches": c_.split(batch), "noise_floor": nz,
+                                                "gate": "builder-defined: max(north_star's 1e-3, 2 x noise_floor)" if dtype_name == "f16" else "builder-defined: max(2e-2, 10 x noise_floor)"})
                 elif O is not None and n_rows > 0:
                     rows_ = parity_rows(c_, batch, n_rows)
                     ci = d_in[rows_].cpu().numpy()
